@@ -1,0 +1,137 @@
+/* embrace_hip.h -- C ABI of libembrace_hip.so (gfx950 / MI355X).
+ *
+ * Drop-in boundary for ONE path of the reference
+ * (nikiiny/Prediction-of-Active-and-Inactive-Regulatory-Regions-with-Embracenet-Multimodal-Neural-Network-):
+ * EmbraceNet docking -> ReLU -> multinomial modality selection -> masked-sum fusion -> post MLP ->
+ * 2-class weighted cross-entropy, forward and backward, plus the optimizer step.
+ * The reference has no FFI of its own (it is pure Python on ATen); each entry point below names the
+ * reference lines (relative to /root/reference/BIOINF_tesi/models/) it replaces.
+ *
+ * Conventions
+ *  - plain pointers and sizes only; every pointer is DEVICE memory unless marked "host";
+ *  - the caller owns every buffer; the library allocates nothing and keeps no state besides a
+ *    thread-local error string;
+ *  - every call only ENQUEUES work on `stream` (a hipStream_t passed as void*), never synchronises,
+ *    never reads device memory from the host -> safe under hipGraph stream capture;
+ *  - return value: 0 on success, negative EMB_ERR_* otherwise (text via emb_last_error());
+ *  - dtype: EMB_F32 | EMB_BF16 | EMB_F64 is the storage type of activations and weights ("T").
+ *    "P" is the parameter/gradient type: float for EMB_F32 and EMB_BF16 (bf16 weights are shadows
+ *    of fp32 masters), double for EMB_F64.  Accumulation is fp32 (fp64 for EMB_F64).
+ *  - matrices are dense row-major; weights use the nn.Linear layout [out_features, in_features];
+ *  - 16-byte alignment of every base pointer is required (torch allocations satisfy it).
+ *
+ * RNG contract (perf mode; parity mode injects the host generator's uniforms instead):
+ *  Philox4x32-10, key = seed, counter = (index.lo, index.hi, stream.lo, stream.hi) with
+ *  stream = (step << 8) | kind and step = step_val + (step_dev ? *step_dev : 0).
+ *  kinds: 0 selection uniform of element (global_row * c + j) -> 53-bit double from words 0,1;
+ *         1 modality-dropout gate (index 0) -> 24-bit float from word 0;
+ *         2 per-row dropped-modality draw (index global_row) -> 24-bit float from word 0;
+ *         16+L activation-dropout mask of layer L (index global_row * N + j) -> 24-bit float.
+ *  Keying on GLOBAL rows makes every draw invariant to how the batch is sharded over GPUs.
+ */
+#ifndef EMBRACE_HIP_H_
+#define EMBRACE_HIP_H_
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define EMB_ABI_VERSION 1
+
+enum { EMB_F32 = 0, EMB_BF16 = 1, EMB_F64 = 2 };
+enum { EMB_OK = 0, EMB_ERR_ARG = -1, EMB_ERR_DTYPE = -2, EMB_ERR_ALIGN = -3, EMB_ERR_LAUNCH = -4 };
+enum { EMB_RNG_SELECT = 0, EMB_RNG_GATE = 1, EMB_RNG_ROWMOD = 2, EMB_RNG_DROPOUT0 = 16 };
+/* bits of the per-element code byte written by emb_embrace_fwd */
+enum { EMB_CODE_IDX = 1, EMB_CODE_ACTIVE = 2 };
+/* bits of the status word */
+enum { EMB_STATUS_INVALID_DISTRIBUTION = 1 };
+
+typedef void* emb_stream_t; /* hipStream_t */
+
+int emb_abi_version(void);
+const char* emb_last_error(void);
+
+/* EmbraceNetMultimodal.py:63-76 (availability * probability, renormalise), :178-184 (modality dropout,
+ * selection-probability broadcast) and the cdf construction inside torch.multinomial (:84).
+ *   p        [p_rows, 2] fp32, p_rows == 1 (broadcast, :184) or B
+ *   avail    [B, 2] fp32 or NULL (all available, :64-65); ignored when device_dropout != 0
+ *   device_dropout != 0: draw the gate r and the per-row dropped modality in-kernel (RNG kinds 1, 2)
+ *            with the reference's semantics: r >= 0.5 -> avail = one_hot(round(rand[row]))
+ *   cdf0     [B] fp32 out: the threshold torch.multinomial compares its uniforms with;
+ *            NaN marks an invalid row and sets EMB_STATUS_INVALID_DISTRIBUTION in *status (atomic or)
+ *   row0     global index of local row 0 (data-parallel shard offset) */
+int emb_select_prep(const float* p, int p_rows, const float* avail, int device_dropout,
+                    uint64_t seed, uint64_t step_val, const uint64_t* step_dev, int64_t row0,
+                    float* cdf0, int32_t* status, int B, emb_stream_t stream);
+
+/* EmbraceNetMultimodal.py:52-60 (docking Linear + ReLU, both modalities), :80 (stack), :84 (multinomial),
+ * :85 (one_hot), :87-88 (mul, sum) -- one fused kernel, nothing [B,c,M]-shaped is materialised.
+ *   X0 [B,d0] T, X1 [B,d1] T, W0 [c,d0] T, W1 [c,d1] T, b0,b1 [c] P
+ *   cdf0 [B] fp32 from emb_select_prep
+ *   u    [B,c] fp64 uniforms of the host generator (parity mode) or NULL -> Philox kind 0
+ *   E    [B,c] T out;  code [B,c] u8 out (EMB_CODE_* bits; idx is bit 0) */
+int emb_embrace_fwd(const void* X0, const void* X1, const void* W0, const void* b0, const void* W1,
+                    const void* b1, const float* cdf0, const double* u, uint64_t seed, uint64_t step_val,
+                    const uint64_t* step_dev, int64_t row0, void* E, uint8_t* code, int B, int d0, int d1,
+                    int c, int dtype, emb_stream_t stream);
+
+/* autograd of the above (loss.backward(), utils/training_models_multimodal.py:156):
+ *   dD_m = dE * [idx == m] * [pre_m > 0];  dW_m = dD_m^T X_m;  db_m = sum_b dD_m;  dX_m = dD_m W_m
+ *   dE [B,c] T, code [B,c] u8;  dX0 [B,d0] T, dX1 [B,d1] T (either may be NULL: not needed);
+ *   dW0 [c,d0] P, db0 [c] P, dW1 [c,d1] P, db1 [c] P  (overwritten, not accumulated) */
+int emb_embrace_bwd(const void* dE, const uint8_t* code, const void* X0, const void* X1, const void* W0,
+                    const void* W1, void* dX0, void* dX1, void* dW0, void* db0, void* dW1, void* db1, int B,
+                    int d0, int d1, int c, int dtype, emb_stream_t stream);
+
+/* One layer of the post stack, EmbraceNetMultimodal.py:143-147 / :151 (also FFNN_pre.py:25-33):
+ * Y = dropout(relu(X W^T + b)).   X [B,K] T, W [N,K] T, b [N] P, Y [B,N] T.
+ *   relu != 0 applies ReLU; dropout_p > 0 applies an inverted-dropout mask from RNG kind 16+layer_id.
+ *   mask [B,N] u8 out (nullable when relu == 0 and dropout_p == 0): bit0 = pre-activation > 0,
+ *   bit1 = kept by dropout. */
+int emb_linear_fwd(const void* X, const void* W, const void* b, void* Y, uint8_t* mask, int relu,
+                   float dropout_p, int layer_id, uint64_t seed, uint64_t step_val, const uint64_t* step_dev,
+                   int64_t row0, int B, int K, int N, int dtype, emb_stream_t stream);
+
+/* backward of emb_linear_fwd: dZ = dY * mask-derived factor; dX = dZ W; dW = dZ^T X; db = sum_b dZ.
+ *   dX [B,K] T (nullable), dW [N,K] P, db [N] P */
+int emb_linear_bwd(const void* dY, const uint8_t* mask, const void* X, const void* W, void* dX, void* dW,
+                   void* db, int relu, float dropout_p, int B, int K, int N, int dtype, emb_stream_t stream);
+
+/* utils/utils.py:121-140 (per-batch class weights) + nn.CrossEntropyLoss(weight) on output.float()
+ * (utils/training_models_multimodal.py:140-141,151-154) + argmax confusion counts for the per-batch
+ * AUPRC / F1 (utils/utils.py:80-94), device-resident.
+ *   logits [B,2] T, target [B] int64
+ *   class_counts [2] int64: IN -- (positives, rows) of the GLOBAL batch when global_counts != 0
+ *                (filled by an all-reduce under data parallelism), else computed in-kernel and written
+ *   loss  [1] fp32 out: sum_i w[y_i] nll_i / sum_i w[y_i]  (local numerator / global denominator under DP)
+ *   dlogits [B,2] T out (nullable): d loss / d logits
+ *   confusion [4] int64 out (nullable): TP, predicted-positive, positive, n  (accumulated: +=) */
+int emb_weighted_ce(const void* logits, const int64_t* target, int64_t* class_counts, int global_counts,
+                    float* loss, void* dlogits, int64_t* confusion, int B, int dtype, emb_stream_t stream);
+
+/* counts positives of a label shard into class_counts[0..1] = (pos, n) (for the DP all-reduce) */
+int emb_count_labels(const int64_t* target, int64_t* class_counts, int B, emb_stream_t stream);
+
+/* Optimizers (utils/training_models_multimodal.py:318-325, :158): one launch updates a flat
+ * parameter buffer.  param/grad/state are P-typed [n]; shadow (nullable) receives the bf16 copy used by
+ * the EMB_BF16 kernels.  step = step_val + *step_dev (1-based). Weight decay is coupled L2 as in torch. */
+int emb_adam_step(void* param, const void* grad, void* exp_avg, void* exp_avg_sq, void* bf16_shadow,
+                  int64_t n, double lr, double beta1, double beta2, double eps, double weight_decay,
+                  uint64_t step_val, const uint64_t* step_dev, int dtype, emb_stream_t stream);
+int emb_rmsprop_step(void* param, const void* grad, void* square_avg, void* bf16_shadow, int64_t n, double lr,
+                     double alpha, double eps, double weight_decay, int dtype, emb_stream_t stream);
+int emb_nadam_step(void* param, const void* grad, void* exp_avg, void* exp_avg_sq, double* m_schedule,
+                   void* bf16_shadow, int64_t n, double lr, double beta1, double beta2, double eps,
+                   double weight_decay, double schedule_decay, uint64_t step_val, const uint64_t* step_dev,
+                   int dtype, emb_stream_t stream);
+
+/* helpers: dtype conversion (fp32/fp64 master -> bf16 shadow etc.) and a device step counter */
+int emb_cast(const void* src, int src_dtype, void* dst, int dst_dtype, int64_t n, emb_stream_t stream);
+int emb_counter_add(uint64_t* counter, uint64_t inc, emb_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* EMBRACE_HIP_H_ */

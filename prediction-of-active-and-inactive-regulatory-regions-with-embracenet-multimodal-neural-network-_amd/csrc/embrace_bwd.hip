@@ -1,0 +1,144 @@
+// EmbraceNet backward in ONE launch: for each modality m
+//   dD_m = dE * [idx == m] * [pre_m > 0]          (never materialised: applied while dE is staged)
+//   dX_m = dD_m   W_m          "dgrad"  M=B, N=d_m, K=c   A = dE row-major,  B = W_m K-major
+//   dW_m = dD_m^T X_m          "wgrad"  M=c, N=d_m, K=B   A = dE K-major,    B = X_m K-major
+//   db_m = sum_b dD_m          folded into wgrad as one extra output column (B gets a virtual ones row)
+// Replaces autograd through EmbraceNetMultimodal.py:52-60,80-88 (loss.backward(),
+// utils/training_models_multimodal.py:156).  The grid is the concatenation of the four tile lists,
+// heaviest (modality 1) first.
+//
+// Each of the four jobs is its own by-value kernel argument read at constant offsets.  (A single
+// argument struct indexed by a run-time modality made hipcc 7.2 re-associate the kernarg address into a
+// byte-granular scalar base, which s_load does not honour: the loaded pointers were garbage.)
+#include "gemm_tile.h"
+
+namespace emb {
+
+template <typename T> struct BwdCfg;
+template <> struct BwdCfg<float> {
+  using D = TileCfg<float, 64, 64, 32, 2, 2, 1, false, true>;
+  using W = TileCfg<float, 64, 64, 32, 2, 2, 1, true, true>;
+};
+template <> struct BwdCfg<double> {
+  using D = TileCfg<double, 64, 64, 16, 2, 2, 1, false, true>;
+  using W = TileCfg<double, 64, 64, 16, 2, 2, 1, true, true>;
+};
+template <> struct BwdCfg<__bf16> {
+  using D = TileCfg<__bf16, 64, 64, 64, 2, 2, 1, false, true>;
+  using W = TileCfg<__bf16, 64, 64, 64, 2, 2, 1, true, true>;
+};
+
+// one GEMM of the backward pass: C[M,N] = mask(dE) . B^T
+template <typename T, typename OutT> struct BwdJob {
+  const T* Bptr;     // W_m (dgrad) or X_m (wgrad), K-major
+  OutT* C;           // dX_m or dW_m
+  OutT* extra;       // db_m (wgrad) or nullptr
+  int M, N, K;
+  int ldb;           // = d_m
+  int tiles_n;
+  int end;           // exclusive end of this job's block range
+  int want;          // XfEmbraceMask::want
+  int vec_b, vec_c;  // 16-byte loads of B / 4-wide stores of C legal
+};
+
+template <typename T>
+__global__ __launch_bounds__(kThreads) void embrace_bwd_kernel(const T* __restrict__ dE, const uint8_t* __restrict__ code,
+                                                               int c, int vec_e,
+                                                               const BwdJob<T, T> dg1,
+                                                               const BwdJob<T, typename AccOf<T>::type> wg1,
+                                                               const BwdJob<T, T> dg0,
+                                                               const BwdJob<T, typename AccOf<T>::type> wg0) {
+  using P = typename AccOf<T>::type;
+  using CD = typename BwdCfg<T>::D;
+  using CW = typename BwdCfg<T>::W;
+  extern __shared__ __attribute__((aligned(16))) char arena[];
+  const int bid = blockIdx.x;
+  const GemmOperand<T> A{dE, code, c, vec_e != 0};
+  if (bid < dg1.end) {
+    const int tile = xcd_remap(bid, dg1.end);
+    gemm_tile<CD>(A, GemmOperand<T>{dg1.Bptr, nullptr, dg1.ldb, dg1.vec_b != 0}, dg1.M, dg1.N, dg1.K, tile / dg1.tiles_n,
+                  tile % dg1.tiles_n, XfEmbraceMask{(uint8_t)dg1.want}, -1,
+                  EpiStore<T>{dg1.C, (long)dg1.N, nullptr, dg1.N, dg1.vec_c != 0}, arena);
+  } else if (bid < wg1.end) {
+    const int tile = xcd_remap(bid - dg1.end, wg1.end - dg1.end);
+    gemm_tile<CW>(A, GemmOperand<T>{wg1.Bptr, nullptr, wg1.ldb, wg1.vec_b != 0}, wg1.M, wg1.N, wg1.K, tile / wg1.tiles_n,
+                  tile % wg1.tiles_n, XfEmbraceMask{(uint8_t)wg1.want}, wg1.N,
+                  EpiStore<P>{wg1.C, (long)wg1.N, wg1.extra, wg1.N, wg1.vec_c != 0}, arena);
+  } else if (bid < dg0.end) {
+    const int tile = xcd_remap(bid - wg1.end, dg0.end - wg1.end);
+    gemm_tile<CD>(A, GemmOperand<T>{dg0.Bptr, nullptr, dg0.ldb, dg0.vec_b != 0}, dg0.M, dg0.N, dg0.K, tile / dg0.tiles_n,
+                  tile % dg0.tiles_n, XfEmbraceMask{(uint8_t)dg0.want}, -1,
+                  EpiStore<T>{dg0.C, (long)dg0.N, nullptr, dg0.N, dg0.vec_c != 0}, arena);
+  } else {
+    const int tile = xcd_remap(bid - dg0.end, wg0.end - dg0.end);
+    gemm_tile<CW>(A, GemmOperand<T>{wg0.Bptr, nullptr, wg0.ldb, wg0.vec_b != 0}, wg0.M, wg0.N, wg0.K, tile / wg0.tiles_n,
+                  tile % wg0.tiles_n, XfEmbraceMask{(uint8_t)wg0.want}, wg0.N,
+                  EpiStore<P>{wg0.C, (long)wg0.N, wg0.extra, wg0.N, wg0.vec_c != 0}, arena);
+  }
+}
+
+template <typename T>
+static int bwd_dispatch(const void* dE, const uint8_t* code, const void* X0, const void* X1, const void* W0, const void* W1,
+                        void* dX0, void* dX1, void* dW0, void* db0, void* dW1, void* db1, int B, int d0, int d1, int c,
+                        hipStream_t s) {
+  using P = typename AccOf<T>::type;
+  using CD = typename BwdCfg<T>::D;
+  using CW = typename BwdCfg<T>::W;
+  constexpr int VEC = Elem<T>::VEC;
+  const int vec_e = (c % VEC == 0) && aligned16(dE) && ((reinterpret_cast<uintptr_t>(code) & 7u) == 0);
+  int n = 0;
+  auto dgrad = [&](const void* W, void* dX, int d, int m) {
+    BwdJob<T, T> j{};
+    j.Bptr = (const T*)W; j.C = (T*)dX; j.extra = nullptr;
+    j.M = B; j.N = d; j.K = c; j.ldb = d;
+    j.tiles_n = cdiv(d, CD::BN);
+    if (dX != nullptr) n += cdiv(B, CD::BM) * j.tiles_n;
+    j.end = n;
+    j.want = (m ? EMB_CODE_IDX : 0) | EMB_CODE_ACTIVE;
+    j.vec_b = (d % VEC == 0) && aligned16(W);
+    j.vec_c = (d % 4 == 0) && aligned16(dX);
+    return j;
+  };
+  auto wgrad = [&](const void* X, void* dW, void* db, int d, int m) {
+    BwdJob<T, P> j{};
+    j.Bptr = (const T*)X; j.C = (P*)dW; j.extra = (P*)db;
+    j.M = c; j.N = d; j.K = B; j.ldb = d;
+    j.tiles_n = cdiv(d + 1, CW::BN);
+    n += cdiv(c, CW::BM) * j.tiles_n;
+    j.end = n;
+    j.want = (m ? EMB_CODE_IDX : 0) | EMB_CODE_ACTIVE;
+    j.vec_b = (d % VEC == 0) && aligned16(X);
+    j.vec_c = (d % 4 == 0) && aligned16(dW);
+    return j;
+  };
+  const BwdJob<T, T> dg1 = dgrad(W1, dX1, d1, 1);
+  const BwdJob<T, P> wg1 = wgrad(X1, dW1, db1, d1, 1);
+  const BwdJob<T, T> dg0 = dgrad(W0, dX0, d0, 0);
+  const BwdJob<T, P> wg0 = wgrad(X0, dW0, db0, d0, 0);
+  constexpr int lds = gemm_tile_lds<CD>() > gemm_tile_lds<CW>() ? gemm_tile_lds<CD>() : gemm_tile_lds<CW>();
+  static bool attr_set = false;
+  if (!attr_set && lds > 48 * 1024) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&embrace_bwd_kernel<T>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    attr_set = true;
+  }
+  embrace_bwd_kernel<T><<<n, kThreads, lds, s>>>((const T*)dE, code, c, vec_e, dg1, wg1, dg0, wg0);
+  EMB_CHECK_LAUNCH();
+  return EMB_OK;
+}
+
+}  // namespace emb
+
+extern "C" int emb_embrace_bwd(const void* dE, const uint8_t* code, const void* X0, const void* X1, const void* W0,
+                               const void* W1, void* dX0, void* dX1, void* dW0, void* db0, void* dW1, void* db1, int B,
+                               int d0, int d1, int c, int dtype, emb_stream_t stream) {
+  EMB_CHECK_ARG(dE && code && X0 && X1 && W0 && W1 && dW0 && db0 && dW1 && db1, "emb_embrace_bwd: null pointer");
+  EMB_CHECK_ARG(B > 0 && d0 > 0 && d1 > 0 && c > 0, "emb_embrace_bwd: bad dims B=%d d0=%d d1=%d c=%d", B, d0, d1, c);
+  hipStream_t s = (hipStream_t)stream;
+  switch (dtype) {
+    case EMB_F32: return emb::bwd_dispatch<float>(dE, code, X0, X1, W0, W1, dX0, dX1, dW0, db0, dW1, db1, B, d0, d1, c, s);
+    case EMB_BF16: return emb::bwd_dispatch<__bf16>(dE, code, X0, X1, W0, W1, dX0, dX1, dW0, db0, dW1, db1, B, d0, d1, c, s);
+    case EMB_F64: return emb::bwd_dispatch<double>(dE, code, X0, X1, W0, W1, dX0, dX1, dW0, db0, dW1, db1, B, d0, d1, c, s);
+  }
+  emb::set_error("emb_embrace_bwd: unsupported dtype %d", dtype);
+  return EMB_ERR_DTYPE;
+}

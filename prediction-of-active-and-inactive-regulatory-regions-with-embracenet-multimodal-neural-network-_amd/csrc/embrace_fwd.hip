@@ -1,0 +1,223 @@
+// Fused EmbraceNet forward: docking GEMMs (both modalities) -> bias -> ReLU -> per-element modality
+// selection -> fused output.  Replaces EmbraceNetMultimodal.py:52-60 and :80-88 of the reference; the
+// [B,c,M] stack / one-hot / product temporaries of the reference never exist here.
+//
+// One workgroup owns a BM x BN tile of E.  It runs the K loop twice (K = d0 with X0/W0, K = d1 with
+// X1/W1), keeps both accumulator tiles, parks them in LDS and finishes with a row-major cooperative
+// epilogue: idx = (double)cdf0[row] < u[row][col] (u injected, or Philox keyed on the global element
+// index), pre = acc_idx + b_idx[col], E = max(pre, 0), code = idx | (pre > 0) << 1.
+#include "gemm_core.h"
+#include "philox.h"
+
+namespace emb {
+
+template <class Cfg>
+__global__ __launch_bounds__(kThreads) void embrace_fwd_kernel(
+    const typename Cfg::T* __restrict__ X0, const typename Cfg::T* __restrict__ X1,
+    const typename Cfg::T* __restrict__ W0, const typename Cfg::T* __restrict__ W1,
+    const typename Cfg::M::Acc* __restrict__ b0, const typename Cfg::M::Acc* __restrict__ b1,
+    const float* __restrict__ cdf0, const double* __restrict__ u, uint64_t seed, uint64_t step_val,
+    const uint64_t* __restrict__ step_dev, int64_t grow0, typename Cfg::T* __restrict__ E,
+    uint8_t* __restrict__ code, int B, int d0, int d1, int c, int tiles_n, int ntiles, bool vec0, bool vec1,
+    bool vec_c) {
+  using T = typename Cfg::T;
+  using M = typename Cfg::M;
+  using Acc = typename M::Acc;
+  extern __shared__ __attribute__((aligned(16))) char arena[];
+
+  const int tile = xcd_remap(blockIdx.x, ntiles);
+  const int tm = tile / tiles_n, tn = tile % tiles_n;
+  const int row0 = tm * Cfg::BM, col0 = tn * Cfg::BN;
+
+  typename M::AccV acc0[Cfg::MI][Cfg::NI], acc1[Cfg::MI][Cfg::NI];
+  zero_acc<Cfg>(acc0);
+  zero_acc<Cfg>(acc1);
+  {
+    Stager<T, false, Cfg::BM, Cfg::BK, XfNone> sa{X0, nullptr, d0, row0, B, d0, vec0, XfNone{}, -1};
+    Stager<T, false, Cfg::BN, Cfg::BK, XfNone> sb{W0, nullptr, d0, col0, c, d0, vec0, XfNone{}, -1};
+    gemm_mainloop<Cfg>(sa, sb, d0, arena, acc0);
+  }
+  {
+    Stager<T, false, Cfg::BM, Cfg::BK, XfNone> sa{X1, nullptr, d1, row0, B, d1, vec1, XfNone{}, -1};
+    Stager<T, false, Cfg::BN, Cfg::BK, XfNone> sb{W1, nullptr, d1, col0, c, d1, vec1, XfNone{}, -1};
+    gemm_mainloop<Cfg>(sa, sb, d1, arena, acc1);
+  }
+  Acc* cs0 = reinterpret_cast<Acc*>(arena);
+  Acc* cs1 = cs0 + Cfg::SLAB;
+  reduce_to_slab<Cfg>(acc0, cs0);
+  reduce_to_slab<Cfg>(acc1, cs1);
+
+  const uint64_t stream = rng_stream(step_val + (step_dev ? *step_dev : 0), EMB_RNG_SELECT);
+  constexpr int GROUPS = Cfg::BM * Cfg::BN / 4;
+  for (int gidx = threadIdx.x; gidx < GROUPS; gidx += kThreads) {
+    const int r = gidx / (Cfg::BN / 4), cq = (gidx % (Cfg::BN / 4)) * 4;
+    const int row = row0 + r, col = col0 + cq;
+    if (row >= B || col >= c) continue;
+    const double thr = (double)cdf0[row];
+    const long base = (long)row * c + col;
+    const int nval = min(4, c - col);
+    double uu[4];
+    if (u != nullptr) {
+      if (nval == 4 && vec_c) {
+        const f64x2 a = *reinterpret_cast<const f64x2*>(u + base);
+        const f64x2 b = *reinterpret_cast<const f64x2*>(u + base + 2);
+        uu[0] = a[0]; uu[1] = a[1]; uu[2] = b[0]; uu[3] = b[1];
+      } else {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) uu[j] = j < nval ? u[base + j] : 0.0;
+      }
+    } else {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const Philox4 ph = philox4x32_10(seed, stream, (uint64_t)(grow0 + row) * (uint64_t)c + (uint64_t)(col + j));
+        uu[j] = uniform53(ph.x, ph.y);
+      }
+    }
+    T ev[4];
+    uint8_t cv[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const bool sel1 = thr < uu[j];   // first slot with cdf >= u (ATen binary search, M = 2)
+      const int cc = min(col + j, c - 1);
+      const Acc pre = sel1 ? cs1[r * Cfg::CS + cq + j] + b1[cc] : cs0[r * Cfg::CS + cq + j] + b0[cc];
+      const bool act = pre > (Acc)0;
+      ev[j] = (T)(act ? pre : (Acc)0);
+      cv[j] = (uint8_t)((sel1 ? EMB_CODE_IDX : 0) | (act ? EMB_CODE_ACTIVE : 0));
+    }
+    if (nval == 4 && vec_c) {
+      typedef T TV4 __attribute__((ext_vector_type(4)));
+      TV4 o = {ev[0], ev[1], ev[2], ev[3]};
+      *reinterpret_cast<TV4*>(E + base) = o;
+      *reinterpret_cast<uint32_t*>(code + base) = (uint32_t)cv[0] | ((uint32_t)cv[1] << 8) | ((uint32_t)cv[2] << 16) | ((uint32_t)cv[3] << 24);
+    } else {
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+        if (j < nval) {
+          E[base + j] = ev[j];
+          code[base + j] = cv[j];
+        }
+    }
+  }
+}
+
+// EmbraceNetMultimodal.py:63-76, :178-184 and the cdf torch.multinomial builds from the row.
+__global__ __launch_bounds__(kThreads) void select_prep_kernel(const float* __restrict__ p, int p_rows,
+                                                               const float* __restrict__ avail, int device_dropout,
+                                                               uint64_t seed, uint64_t step_val,
+                                                               const uint64_t* __restrict__ step_dev, int64_t grow0,
+                                                               float* __restrict__ cdf0, int32_t* __restrict__ status,
+                                                               int B) {
+  const int row = blockIdx.x * blockDim.x + threadIdx.x;
+  if (row >= B) return;
+  const float* pr = p + (p_rows == 1 ? 0 : 2 * (long)row);
+  float a0 = 1.0f, a1 = 1.0f;
+  if (device_dropout) {
+    const uint64_t step = step_val + (step_dev ? *step_dev : 0);
+    const float gate = uniform24(philox4x32_10(seed, rng_stream(step, EMB_RNG_GATE), 0).x);
+    if (gate >= 0.5f) {   // EmbraceNetMultimodal.py:180
+      const float t = uniform24(philox4x32_10(seed, rng_stream(step, EMB_RNG_ROWMOD), (uint64_t)(grow0 + row)).x);
+      const bool m1 = t > 0.5f;   // torch.round: half-to-even, 0.5 -> 0   (:181)
+      a0 = m1 ? 0.0f : 1.0f;
+      a1 = m1 ? 1.0f : 0.0f;
+    }
+  } else if (avail != nullptr) {
+    a0 = avail[2 * (long)row];
+    a1 = avail[2 * (long)row + 1];
+  }
+  // every operation below is a separately rounded fp32 op, as in the reference's ATen calls
+  const float q0 = __fmul_rn(pr[0], a0), q1 = __fmul_rn(pr[1], a1);   // :73
+  const float s = __fadd_rn(q0, q1);                                   // :75
+  const float n0 = __fdiv_rn(q0, s), n1 = __fdiv_rn(q1, s);            // :76
+  // torch.multinomial (ATen CPU kernel): running sum, then cum /= sum
+  const float tot = __fadd_rn(n0, n1);
+  float cdf = __fdiv_rn(n0, tot);
+  const bool ok = (n0 >= 0.0f) && (n1 >= 0.0f) && isfinite(n0) && isfinite(n1) && (tot > 0.0f);
+  if (!ok) {
+    cdf = __builtin_nanf("");
+    atomicOr(status, EMB_STATUS_INVALID_DISTRIBUTION);
+  }
+  cdf0[row] = cdf;
+}
+
+// ----------------------------------------------------------------------------------- dispatch
+template <class Cfg> static int launch_fwd(const void* X0, const void* X1, const void* W0, const void* b0, const void* W1,
+                                           const void* b1, const float* cdf0, const double* u, uint64_t seed,
+                                           uint64_t step_val, const uint64_t* step_dev, int64_t row0, void* E, uint8_t* code,
+                                           int B, int d0, int d1, int c, hipStream_t s) {
+  using T = typename Cfg::T;
+  using Acc = typename Cfg::M::Acc;
+  constexpr int VEC = Elem<T>::VEC;
+  const int tiles_m = cdiv(B, Cfg::BM), tiles_n = cdiv(c, Cfg::BN), ntiles = tiles_m * tiles_n;
+  const bool vec0 = (d0 % VEC == 0) && aligned16(X0) && aligned16(W0);
+  const bool vec1 = (d1 % VEC == 0) && aligned16(X1) && aligned16(W1);
+  const bool vec_c = (c % 4 == 0) && aligned16(E) && aligned16(u) && ((reinterpret_cast<uintptr_t>(code) & 3u) == 0);
+  constexpr int slab_bytes = 2 * Cfg::SLAB * (int)sizeof(Acc);
+  constexpr int lds = Cfg::OPERAND_BYTES > slab_bytes ? Cfg::OPERAND_BYTES : slab_bytes;
+  static bool attr_set = false;
+  if (!attr_set && lds > 48 * 1024) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&embrace_fwd_kernel<Cfg>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    attr_set = true;
+  }
+  embrace_fwd_kernel<Cfg><<<ntiles, kThreads, lds, s>>>(
+      (const T*)X0, (const T*)X1, (const T*)W0, (const T*)W1, (const Acc*)b0, (const Acc*)b1, cdf0, u, seed, step_val,
+      step_dev, row0, (T*)E, code, B, d0, d1, c, tiles_n, ntiles, vec0, vec1, vec_c);
+  EMB_CHECK_LAUNCH();
+  return EMB_OK;
+}
+
+// tile shapes: "L" 64x64 tile, 2x2 waves, for tile counts that fill the chip; "S" 32x32 tile with
+// the K range split over the 4 waves, for small B*c with long K (the A549 shapes: B=1024, c=256..512)
+template <typename T> struct FwdCfg;
+template <> struct FwdCfg<float> {
+  using L = TileCfg<float, 64, 64, 32, 2, 2, 1, false, false>;
+  using S = TileCfg<float, 32, 32, 128, 1, 1, 4, false, false>;
+};
+template <> struct FwdCfg<double> {
+  using L = TileCfg<double, 64, 64, 16, 2, 2, 1, false, false>;
+  using S = TileCfg<double, 32, 32, 64, 1, 1, 4, false, false>;
+};
+template <> struct FwdCfg<__bf16> {
+  using L = TileCfg<__bf16, 64, 64, 128, 2, 2, 1, false, false>;
+  using S = TileCfg<__bf16, 32, 32, 256, 1, 1, 4, false, false>;
+};
+
+template <typename T> static int fwd_dispatch(const void* X0, const void* X1, const void* W0, const void* b0, const void* W1,
+                                              const void* b1, const float* cdf0, const double* u, uint64_t seed,
+                                              uint64_t step_val, const uint64_t* step_dev, int64_t row0, void* E,
+                                              uint8_t* code, int B, int d0, int d1, int c, hipStream_t s) {
+  const long tiles_L = (long)cdiv(B, 64) * cdiv(c, 64);
+  if (tiles_L >= 192)
+    return launch_fwd<typename FwdCfg<T>::L>(X0, X1, W0, b0, W1, b1, cdf0, u, seed, step_val, step_dev, row0, E, code, B, d0, d1, c, s);
+  return launch_fwd<typename FwdCfg<T>::S>(X0, X1, W0, b0, W1, b1, cdf0, u, seed, step_val, step_dev, row0, E, code, B, d0, d1, c, s);
+}
+
+}  // namespace emb
+
+extern "C" int emb_select_prep(const float* p, int p_rows, const float* avail, int device_dropout, uint64_t seed,
+                               uint64_t step_val, const uint64_t* step_dev, int64_t row0, float* cdf0, int32_t* status,
+                               int B, emb_stream_t stream) {
+  EMB_CHECK_ARG(p && cdf0 && status, "emb_select_prep: null pointer");
+  EMB_CHECK_ARG(B >= 0 && (p_rows == 1 || p_rows == B), "emb_select_prep: p_rows must be 1 or B (got %d, B=%d)", p_rows, B);
+  if (B == 0) return EMB_OK;
+  emb::select_prep_kernel<<<emb::cdiv(B, emb::kThreads), emb::kThreads, 0, (hipStream_t)stream>>>(
+      p, p_rows, avail, device_dropout, seed, step_val, step_dev, row0, cdf0, status, B);
+  EMB_CHECK_LAUNCH();
+  return EMB_OK;
+}
+
+extern "C" int emb_embrace_fwd(const void* X0, const void* X1, const void* W0, const void* b0, const void* W1,
+                               const void* b1, const float* cdf0, const double* u, uint64_t seed, uint64_t step_val,
+                               const uint64_t* step_dev, int64_t row0, void* E, uint8_t* code, int B, int d0, int d1, int c,
+                               int dtype, emb_stream_t stream) {
+  EMB_CHECK_ARG(X0 && X1 && W0 && W1 && b0 && b1 && cdf0 && E && code, "emb_embrace_fwd: null pointer");
+  EMB_CHECK_ARG(B >= 0 && d0 > 0 && d1 > 0 && c > 0, "emb_embrace_fwd: bad dims B=%d d0=%d d1=%d c=%d", B, d0, d1, c);
+  if (B == 0) return EMB_OK;
+  hipStream_t s = (hipStream_t)stream;
+  switch (dtype) {
+    case EMB_F32: return emb::fwd_dispatch<float>(X0, X1, W0, b0, W1, b1, cdf0, u, seed, step_val, step_dev, row0, E, code, B, d0, d1, c, s);
+    case EMB_BF16: return emb::fwd_dispatch<__bf16>(X0, X1, W0, b0, W1, b1, cdf0, u, seed, step_val, step_dev, row0, E, code, B, d0, d1, c, s);
+    case EMB_F64: return emb::fwd_dispatch<double>(X0, X1, W0, b0, W1, b1, cdf0, u, seed, step_val, step_dev, row0, E, code, B, d0, d1, c, s);
+  }
+  emb::set_error("emb_embrace_fwd: unsupported dtype %d", dtype);
+  return EMB_ERR_DTYPE;
+}

@@ -1,0 +1,292 @@
+// Step epilogue kernels: per-batch class weights + weighted 2-class cross-entropy + confusion counts
+// (utils/utils.py:121-140, :80-94; utils/training_models_multimodal.py:140-141,151-154), the optimizers
+// the reference can pick (utils/training_models_multimodal.py:318-325: Adam, RMSprop from torch, Nadam
+// from timm), dtype casts and the device step counter.  All bandwidth-trivial; written so that no value
+// ever has to visit the host during a step (hipGraph-capturable).
+#include "common.h"
+
+namespace emb {
+
+template <typename V> __device__ __forceinline__ V block_sum(V v, V* scratch) {
+  // fixed-order tree reduction: deterministic for a given block size
+  const int tid = threadIdx.x;
+  scratch[tid] = v;
+  __syncthreads();
+  for (int s = blockDim.x >> 1; s > 0; s >>= 1) {
+    if (tid < s) scratch[tid] += scratch[tid + s];
+    __syncthreads();
+  }
+  const V r = scratch[0];
+  __syncthreads();
+  return r;
+}
+
+constexpr int kCeThreads = 1024;
+
+template <typename T>
+__global__ __launch_bounds__(kCeThreads) void weighted_ce_kernel(const T* __restrict__ logits, const int64_t* __restrict__ target,
+                                                                 int64_t* __restrict__ class_counts, int global_counts,
+                                                                 float* __restrict__ loss, T* __restrict__ dlogits,
+                                                                 int64_t* __restrict__ confusion, int B) {
+  __shared__ double sd[kCeThreads];
+  __shared__ long long sl[kCeThreads];
+  const int tid = threadIdx.x;
+  long long pos_l = 0;
+  for (int i = tid; i < B; i += kCeThreads) pos_l += (target[i] == 1);
+  const long long pos_local = block_sum<long long>(pos_l, sl);
+  long long pos = pos_local, n = B;
+  if (global_counts) {
+    pos = class_counts[0];
+    n = class_counts[1];
+  } else if (tid == 0) {
+    class_counts[0] = pos;
+    class_counts[1] = n;
+  }
+  const long long neg = n - pos;
+  // utils/utils.py:134-140 in double, then torch.tensor([w_neg, w_pos]) -> fp32
+  const double pos_inv = pos != 0 ? 1.0 / (double)pos : 0.0;
+  const double neg_inv = neg != 0 ? 1.0 / (double)neg : 0.0;
+  const float w1 = (float)(pos_inv / (neg_inv + pos_inv));   // weight of class 1
+  const float w0 = (float)(neg_inv / (neg_inv + pos_inv));   // weight of class 0
+  const double den = (double)w1 * (double)pos + (double)w0 * (double)neg;   // sum_i w[y_i] over the global batch
+  double num_l = 0.0;
+  long long tp_l = 0, pp_l = 0;
+  for (int i = tid; i < B; i += kCeThreads) {
+    const float z0 = (float)logits[2 * (long)i], z1 = (float)logits[2 * (long)i + 1];   // output.float()
+    const int y = target[i] == 1 ? 1 : 0;
+    const float zm = fmaxf(z0, z1);
+    const float e0 = expf(z0 - zm), e1 = expf(z1 - zm);
+    const float lse = zm + logf(e0 + e1);
+    const float wy = y ? w1 : w0;
+    num_l += (double)wy * (double)(lse - (y ? z1 : z0));
+    const int pred = z1 > z0 ? 1 : 0;   // torch.argmax: first maximum wins ties
+    tp_l += (pred & y);
+    pp_l += pred;
+    if (dlogits != nullptr) {
+      const float inv = 1.0f / (e0 + e1);
+      const float g = (float)((double)wy / den);
+      dlogits[2 * (long)i] = (T)(g * (e0 * inv - (y ? 0.0f : 1.0f)));
+      dlogits[2 * (long)i + 1] = (T)(g * (e1 * inv - (y ? 1.0f : 0.0f)));
+    }
+  }
+  const double num = block_sum<double>(num_l, sd);
+  const long long tp = block_sum<long long>(tp_l, sl);
+  const long long pp = block_sum<long long>(pp_l, sl);
+  if (tid == 0) {
+    loss[0] = (float)(num / den);
+    if (confusion != nullptr) {
+      confusion[0] += tp;
+      confusion[1] += pp;
+      confusion[2] += pos_local;
+      confusion[3] += B;
+    }
+  }
+}
+
+__global__ __launch_bounds__(kCeThreads) void count_labels_kernel(const int64_t* __restrict__ target, int64_t* __restrict__ cc, int B) {
+  __shared__ long long sl[kCeThreads];
+  long long p = 0;
+  for (int i = threadIdx.x; i < B; i += kCeThreads) p += (target[i] == 1);
+  const long long pos = block_sum<long long>(p, sl);
+  if (threadIdx.x == 0) {
+    cc[0] = pos;
+    cc[1] = B;
+  }
+}
+
+// ------------------------------------------------------------------------------------ optimizers
+template <typename P>
+__global__ void adam_kernel(P* __restrict__ p, const P* __restrict__ g, P* __restrict__ m, P* __restrict__ v,
+                            __bf16* __restrict__ shadow, int64_t n, double lr, double b1, double b2, double eps, double wd,
+                            uint64_t step_val, const uint64_t* __restrict__ step_dev) {
+  const double step = (double)(step_val + (step_dev ? *step_dev : 0));
+  const double bc1 = 1.0 - pow(b1, step), bc2 = 1.0 - pow(b2, step);
+  const P step_size = (P)(lr / bc1), bc2s = (P)sqrt(bc2);
+  const P pb1 = (P)b1, pb2 = (P)b2, pwd = (P)wd, peps = (P)eps, omb1 = (P)(1.0 - b1), omb2 = (P)(1.0 - b2);
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    P pi = p[i];
+    const P gi = g[i] + pwd * pi;                 // coupled L2 (torch.optim.Adam weight_decay)
+    const P mi = m[i] + (gi - m[i]) * omb1;       // lerp
+    const P vi = v[i] * pb2 + gi * gi * omb2;
+    const P denom = sqrt(vi) / bc2s + peps;
+    pi -= step_size * (mi / denom);
+    p[i] = pi; m[i] = mi; v[i] = vi;
+    if (shadow) shadow[i] = (__bf16)(float)pi;
+  }
+}
+
+template <typename P>
+__global__ void rmsprop_kernel(P* __restrict__ p, const P* __restrict__ g, P* __restrict__ sq, __bf16* __restrict__ shadow,
+                               int64_t n, double lr, double alpha, double eps, double wd) {
+  const P pa = (P)alpha, oma = (P)(1.0 - alpha), pwd = (P)wd, peps = (P)eps, plr = (P)lr;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    P pi = p[i];
+    const P gi = g[i] + pwd * pi;
+    const P si = sq[i] * pa + gi * gi * oma;
+    pi -= plr * (gi / (sqrt(si) + peps));
+    p[i] = pi; sq[i] = si;
+    if (shadow) shadow[i] = (__bf16)(float)pi;
+  }
+}
+
+// timm.optim.Nadam (not installed in this image: restated from its published algorithm -- Dozat 2016
+// with the warm momentum schedule mu_t = beta1 (1 - 0.5 * 0.96^(t * schedule_decay))).  m_schedule is a
+// two-slot ping-pong (read slot (t+1)&1, write slot t&1) so that no thread reads what another writes.
+template <typename P>
+__global__ void nadam_kernel(P* __restrict__ p, const P* __restrict__ g, P* __restrict__ m, P* __restrict__ v,
+                             double* __restrict__ m_schedule, __bf16* __restrict__ shadow, int64_t n, double lr, double b1,
+                             double b2, double eps, double wd, double sdecay, uint64_t step_val,
+                             const uint64_t* __restrict__ step_dev) {
+  const uint64_t t = step_val + (step_dev ? *step_dev : 0);
+  const double td = (double)t;
+  const double mu_t = b1 * (1.0 - 0.5 * pow(0.96, td * sdecay));
+  const double mu_n = b1 * (1.0 - 0.5 * pow(0.96, (td + 1.0) * sdecay));
+  const double ms_old = m_schedule[(t + 1) & 1];
+  const double ms_new = ms_old * mu_t, ms_next = ms_new * mu_n;
+  const double bc2 = 1.0 - pow(b2, td);
+  const P c_g = (P)(lr * (1.0 - mu_t) / (1.0 - ms_new)), c_m = (P)(lr * mu_n / (1.0 - ms_next));
+  const P bc2s = (P)sqrt(bc2), pb1 = (P)b1, pb2 = (P)b2, omb1 = (P)(1.0 - b1), omb2 = (P)(1.0 - b2), pwd = (P)wd, peps = (P)eps;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    P pi = p[i];
+    const P gi = g[i] + pwd * pi;
+    const P mi = m[i] * pb1 + gi * omb1;
+    const P vi = v[i] * pb2 + gi * gi * omb2;
+    const P denom = sqrt(vi) / bc2s + peps;
+    pi -= c_g * (gi / denom);
+    pi -= c_m * (mi / denom);
+    p[i] = pi; m[i] = mi; v[i] = vi;
+    if (shadow) shadow[i] = (__bf16)(float)pi;
+  }
+  if (blockIdx.x == 0 && threadIdx.x == 0) m_schedule[t & 1] = ms_new;
+}
+
+template <typename S, typename D> __global__ void cast_kernel(const S* __restrict__ s, D* __restrict__ d, int64_t n) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+    if constexpr (sizeof(D) == 2) d[i] = (D)(float)s[i];
+    else d[i] = (D)(typename AccOf<S>::type)s[i];
+}
+
+__global__ void counter_add_kernel(uint64_t* c, uint64_t inc) { *c += inc; }
+
+static inline int ew_grid(int64_t n) {
+  int64_t b = (n + 255) / 256;
+  return (int)(b < 1 ? 1 : (b > 2048 ? 2048 : b));
+}
+
+template <typename S> static int cast_from(const void* src, void* dst, int dd, int64_t n, hipStream_t s) {
+  const int g = ew_grid(n);
+  switch (dd) {
+    case EMB_F32: cast_kernel<S, float><<<g, 256, 0, s>>>((const S*)src, (float*)dst, n); break;
+    case EMB_BF16: cast_kernel<S, __bf16><<<g, 256, 0, s>>>((const S*)src, (__bf16*)dst, n); break;
+    case EMB_F64: cast_kernel<S, double><<<g, 256, 0, s>>>((const S*)src, (double*)dst, n); break;
+    default: set_error("emb_cast: unsupported dst dtype %d", dd); return EMB_ERR_DTYPE;
+  }
+  EMB_CHECK_LAUNCH();
+  return EMB_OK;
+}
+
+}  // namespace emb
+
+using namespace emb;
+
+extern "C" int emb_weighted_ce(const void* logits, const int64_t* target, int64_t* class_counts, int global_counts, float* loss,
+                               void* dlogits, int64_t* confusion, int B, int dtype, emb_stream_t stream) {
+  EMB_CHECK_ARG(logits && target && class_counts && loss, "emb_weighted_ce: null pointer");
+  EMB_CHECK_ARG(B > 0, "emb_weighted_ce: B must be positive (got %d)", B);
+  hipStream_t s = (hipStream_t)stream;
+  switch (dtype) {
+    case EMB_F32: weighted_ce_kernel<float><<<1, kCeThreads, 0, s>>>((const float*)logits, target, class_counts, global_counts, loss, (float*)dlogits, confusion, B); break;
+    case EMB_BF16: weighted_ce_kernel<__bf16><<<1, kCeThreads, 0, s>>>((const __bf16*)logits, target, class_counts, global_counts, loss, (__bf16*)dlogits, confusion, B); break;
+    case EMB_F64: weighted_ce_kernel<double><<<1, kCeThreads, 0, s>>>((const double*)logits, target, class_counts, global_counts, loss, (double*)dlogits, confusion, B); break;
+    default: set_error("emb_weighted_ce: unsupported dtype %d", dtype); return EMB_ERR_DTYPE;
+  }
+  EMB_CHECK_LAUNCH();
+  return EMB_OK;
+}
+
+extern "C" int emb_count_labels(const int64_t* target, int64_t* class_counts, int B, emb_stream_t stream) {
+  EMB_CHECK_ARG(target && class_counts && B >= 0, "emb_count_labels: bad argument");
+  count_labels_kernel<<<1, kCeThreads, 0, (hipStream_t)stream>>>(target, class_counts, B);
+  EMB_CHECK_LAUNCH();
+  return EMB_OK;
+}
+
+extern "C" int emb_adam_step(void* param, const void* grad, void* exp_avg, void* exp_avg_sq, void* bf16_shadow, int64_t n,
+                             double lr, double beta1, double beta2, double eps, double weight_decay, uint64_t step_val,
+                             const uint64_t* step_dev, int dtype, emb_stream_t stream) {
+  EMB_CHECK_ARG(param && grad && exp_avg && exp_avg_sq && n >= 0, "emb_adam_step: bad argument");
+  if (n == 0) return EMB_OK;
+  hipStream_t s = (hipStream_t)stream;
+  if (dtype == EMB_F64)
+    adam_kernel<double><<<ew_grid(n), 256, 0, s>>>((double*)param, (const double*)grad, (double*)exp_avg, (double*)exp_avg_sq, (__bf16*)bf16_shadow, n, lr, beta1, beta2, eps, weight_decay, step_val, step_dev);
+  else if (dtype == EMB_F32 || dtype == EMB_BF16)
+    adam_kernel<float><<<ew_grid(n), 256, 0, s>>>((float*)param, (const float*)grad, (float*)exp_avg, (float*)exp_avg_sq, (__bf16*)bf16_shadow, n, lr, beta1, beta2, eps, weight_decay, step_val, step_dev);
+  else { set_error("emb_adam_step: unsupported dtype %d", dtype); return EMB_ERR_DTYPE; }
+  EMB_CHECK_LAUNCH();
+  return EMB_OK;
+}
+
+extern "C" int emb_rmsprop_step(void* param, const void* grad, void* square_avg, void* bf16_shadow, int64_t n, double lr,
+                                double alpha, double eps, double weight_decay, int dtype, emb_stream_t stream) {
+  EMB_CHECK_ARG(param && grad && square_avg && n >= 0, "emb_rmsprop_step: bad argument");
+  if (n == 0) return EMB_OK;
+  hipStream_t s = (hipStream_t)stream;
+  if (dtype == EMB_F64)
+    rmsprop_kernel<double><<<ew_grid(n), 256, 0, s>>>((double*)param, (const double*)grad, (double*)square_avg, (__bf16*)bf16_shadow, n, lr, alpha, eps, weight_decay);
+  else if (dtype == EMB_F32 || dtype == EMB_BF16)
+    rmsprop_kernel<float><<<ew_grid(n), 256, 0, s>>>((float*)param, (const float*)grad, (float*)square_avg, (__bf16*)bf16_shadow, n, lr, alpha, eps, weight_decay);
+  else { set_error("emb_rmsprop_step: unsupported dtype %d", dtype); return EMB_ERR_DTYPE; }
+  EMB_CHECK_LAUNCH();
+  return EMB_OK;
+}
+
+extern "C" int emb_nadam_step(void* param, const void* grad, void* exp_avg, void* exp_avg_sq, double* m_schedule,
+                              void* bf16_shadow, int64_t n, double lr, double beta1, double beta2, double eps,
+                              double weight_decay, double schedule_decay, uint64_t step_val, const uint64_t* step_dev,
+                              int dtype, emb_stream_t stream) {
+  EMB_CHECK_ARG(param && grad && exp_avg && exp_avg_sq && m_schedule && n >= 0, "emb_nadam_step: bad argument");
+  if (n == 0) return EMB_OK;
+  hipStream_t s = (hipStream_t)stream;
+  if (dtype == EMB_F64)
+    nadam_kernel<double><<<ew_grid(n), 256, 0, s>>>((double*)param, (const double*)grad, (double*)exp_avg, (double*)exp_avg_sq, m_schedule, (__bf16*)bf16_shadow, n, lr, beta1, beta2, eps, weight_decay, schedule_decay, step_val, step_dev);
+  else if (dtype == EMB_F32 || dtype == EMB_BF16)
+    nadam_kernel<float><<<ew_grid(n), 256, 0, s>>>((float*)param, (const float*)grad, (float*)exp_avg, (float*)exp_avg_sq, m_schedule, (__bf16*)bf16_shadow, n, lr, beta1, beta2, eps, weight_decay, schedule_decay, step_val, step_dev);
+  else { set_error("emb_nadam_step: unsupported dtype %d", dtype); return EMB_ERR_DTYPE; }
+  EMB_CHECK_LAUNCH();
+  return EMB_OK;
+}
+
+extern "C" int emb_cast(const void* src, int src_dtype, void* dst, int dst_dtype, int64_t n, emb_stream_t stream) {
+  EMB_CHECK_ARG(src && dst && n >= 0, "emb_cast: bad argument");
+  if (n == 0) return EMB_OK;
+  hipStream_t s = (hipStream_t)stream;
+  switch (src_dtype) {
+    case EMB_F32: return cast_from<float>(src, dst, dst_dtype, n, s);
+    case EMB_BF16: return cast_from<__bf16>(src, dst, dst_dtype, n, s);
+    case EMB_F64: return cast_from<double>(src, dst, dst_dtype, n, s);
+  }
+  set_error("emb_cast: unsupported src dtype %d", src_dtype);
+  return EMB_ERR_DTYPE;
+}
+
+extern "C" int emb_counter_add(uint64_t* counter, uint64_t inc, emb_stream_t stream) {
+  EMB_CHECK_ARG(counter, "emb_counter_add: null pointer");
+  counter_add_kernel<<<1, 1, 0, (hipStream_t)stream>>>(counter, inc);
+  EMB_CHECK_LAUNCH();
+  return EMB_OK;
+}
+
+// ------------------------------------------------------------------------------ library plumbing
+#include <cstdarg>
+#include <cstdio>
+namespace emb {
+static thread_local char g_err[512] = "";
+void set_error(const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof(g_err), fmt, ap);
+  va_end(ap);
+}
+}  // namespace emb
+extern "C" int emb_abi_version(void) { return EMB_ABI_VERSION; }
+extern "C" const char* emb_last_error(void) { return emb::g_err; }

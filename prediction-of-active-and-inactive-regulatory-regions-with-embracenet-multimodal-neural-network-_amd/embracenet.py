@@ -1,0 +1,216 @@
+"""EmbraceNet fusion module and the multimodal classifier built on it -- drop-in interface of
+BIOINF_tesi/models/EmbraceNetMultimodal.py (EmbraceNet :12-90, EmbraceNetMultimodal :94-193),
+executed by hand-written gfx950 kernels (csrc/).  Same class names, constructor/forward signatures,
+parameter names and shapes (``embracenet.docking_{0,1}.{weight,bias}``, ``post.{3i}.*``), same
+Optuna ``trial`` call order, same errors (AssertionError on a modality-count mismatch, RuntimeError on
+an invalid selection distribution).
+
+RNG
+---
+``rng_mode == "host"``  (parity mode): every random number is drawn from a CPU ``torch.Generator`` in
+  exactly the reference's order -- rand(1) fp32, rand(B) fp32 (modality dropout, :179-181), then the
+  B*c fp64 uniforms torch.multinomial consumes (:84) -- and injected into the kernel, which reproduces
+  the CPU index tensor bit for bit.
+``rng_mode == "philox"`` (default): the kernels draw from Philox4x32-10 keyed on (seed, step, global
+  element index); no host round trip, no device->host sync, graph-capturable, invariant to how the batch
+  is sharded across GPUs.
+"""
+import torch
+import torch.nn as nn
+
+from . import functional as F_
+from ._lib import STATUS_INVALID_DISTRIBUTION
+from .prenets import CNN_pre, FFNN_pre
+
+
+class _RngMixin:
+    def _init_rng(self):
+        self.rng_mode = "philox"
+        self.generator = None          # host mode: CPU generator (None = torch's default CPU generator)
+        self.rng_seed = int(torch.initial_seed()) & 0xFFFFFFFFFFFFFFFF
+        self.rng_row0 = 0              # global index of local row 0 (data parallel)
+        self._step_dev = None          # uint64-as-int64 device counter, created lazily
+        self.check_distribution = None  # None: check (sync) in host mode only
+
+    def set_rng(self, mode, generator=None, seed=None, row0=None):
+        if mode not in ("host", "philox"):
+            raise ValueError("rng mode must be 'host' or 'philox'")
+        self.rng_mode, self.generator = mode, generator
+        if seed is not None:
+            self.rng_seed = int(seed) & 0xFFFFFFFFFFFFFFFF
+        if row0 is not None:
+            self.rng_row0 = int(row0)
+        return self
+
+    def _rng_state(self, device):
+        if self._step_dev is None or self._step_dev.device != device:
+            self._step_dev = torch.zeros(1, dtype=torch.int64, device=device)
+        return F_.RngState(self.rng_seed, 0, self._step_dev, self.rng_row0)
+
+    def _advance_step(self):
+        from . import _lib
+        _lib.check(_lib.lib().emb_counter_add(self._step_dev.data_ptr(), 1, _lib.stream()), "emb_counter_add")
+
+    def __getstate__(self):
+        st = self.__dict__.copy()
+        for k in ("_step_dev", "generator", "last_code", "last_status", "_sel_dev", "_sel_key"):
+            if k in st:
+                st[k] = None
+        return st
+
+
+class EmbraceNet(nn.Module, _RngMixin):
+    def __init__(self, device, input_size_list, embracement_size=256, bypass_docking=False):
+        super().__init__()
+        self.device = device
+        self.input_size_list = input_size_list
+        self.embracement_size = embracement_size
+        self.bypass_docking = bypass_docking
+        if not bypass_docking:
+            for i, size in enumerate(input_size_list):
+                setattr(self, "docking_%d" % i, nn.Linear(size, embracement_size))
+        self.compute_dtype = None      # None: follow the parameters' dtype; torch.bfloat16: bf16 shadows
+        self.last_code = None          # [B,c] uint8 of the latest forward (bit0 = selected modality)
+        self._init_rng()
+
+    def forward(self, input_list, availabilities=None, selection_probabilities=None, _device_dropout=False,
+                _advance=True):
+        assert len(input_list) == len(self.input_size_list)
+        if len(input_list) != 2:
+            raise NotImplementedError("the gfx950 kernels implement the two-modality EmbraceNet")
+        if self.bypass_docking:
+            raise NotImplementedError("bypass_docking is not part of the accelerated path")
+        x0, x1 = input_list
+        B, c = x0.shape[0], self.embracement_size
+        dev = x0.device
+        T = self.compute_dtype or self.docking_0.weight.dtype
+        rng = self._rng_state(dev)
+
+        if selection_probabilities is None:                       # :70-71
+            selection_probabilities = torch.ones(1, 2, dtype=torch.float32, device=dev)
+        p = selection_probabilities.to(device=dev, dtype=torch.float32)
+        if p.dim() == 2 and p.shape[0] not in (1, B):
+            raise ValueError("selection_probabilities must be [B, M] or [M]")
+        avail = None if availabilities is None else availabilities.to(device=dev, dtype=torch.float32)
+        cdf0, status = F_.select_prep(p, avail, B, rng=rng, device_dropout=_device_dropout)
+
+        u = None
+        if self.rng_mode == "host":                               # replay of torch.multinomial's draws (:84)
+            u = torch.rand(B * c, dtype=torch.float64, generator=self.generator).view(B, c).to(dev, non_blocking=True)
+        check = self.check_distribution if self.check_distribution is not None else (self.rng_mode == "host")
+        if check and int(status.item()) & STATUS_INVALID_DISTRIBUTION:
+            raise RuntimeError("invalid multinomial distribution (encountering probability entry < 0)")
+        self.last_status = status
+
+        E, code = F_.embrace(x0, x1, self.docking_0.weight, self.docking_0.bias, self.docking_1.weight,
+                             self.docking_1.bias, cdf0, u=u, rng=rng, compute_dtype=T)
+        self.last_code = code
+        if _advance:
+            self._advance_step()
+        return E
+
+    def modality_indices(self):
+        """[B, c] int64 index tensor of the latest forward (what torch.multinomial returned in the reference)."""
+        return (self.last_code & 1).to(torch.int64)
+
+
+class EmbraceNetMultimodal(nn.Module, _RngMixin):
+    def __init__(self, trial, cell_line, task, device, in_features_FFNN, n_classes=2, args=None,
+                 embracenet_dropout=True):
+        super().__init__()
+        self.trial = trial
+        self.cell_line = cell_line
+        self.device = device
+        self.n_classes = n_classes
+        self.embracenet_dropout = embracenet_dropout
+        self.args = args
+
+        self.FFNN = FFNN_pre(self.trial, in_features_FFNN, device=self.device)
+        self.CNN = CNN_pre(self.trial, device=self.device)
+        self.FFNN_pre_output_size = self.FFNN.output_size
+        self.CNN_pre_output_size = self.CNN.output_size
+
+        embracement_size = self.trial.suggest_categorical("EMBRACENET_embracement_size", [512, 768, 1024])
+        self.embracenet = EmbraceNet(device=self.device,
+                                     input_size_list=[self.FFNN_pre_output_size, self.CNN_pre_output_size],
+                                     embracement_size=embracement_size)
+
+        n_post_layers = self.trial.suggest_int("n_post_layers", 0, 2)
+        widths = ([32, 64, 128, 256, 512], [16, 32, 64, 128, 256])
+        stack, width = [], embracement_size
+        for i in range(n_post_layers):
+            out = self.trial.suggest_categorical(f"EMBRACENET_n_units_l{i}", widths[i])
+            p = self.trial.suggest_categorical(f"EMBRACENET_dropout_l{i}", [0.0, 0.2, 0.3, 0.5])
+            stack += [nn.Linear(width, out), nn.ReLU(), nn.Dropout(p)]
+            width = out
+        stack.append(nn.Linear(width, self.n_classes))
+        self.post = nn.Sequential(*stack)
+
+        s = self.trial.suggest_float("selection_probabilities_FFNN", 0.0, 1.0)
+        self.selection_probabilities = torch.tensor([s, 1.0 - s])     # plain attribute, not in the state dict (:157)
+        self.compute_dtype = None
+        self._init_rng()
+
+    # -- configuration ---------------------------------------------------------------------------
+    def set_compute_dtype(self, dtype):
+        """None: kernels run in the parameters' dtype (fp32 / fp64).  torch.bfloat16: bf16 activations and
+        weight shadows, fp32 master parameters, fp32 accumulation."""
+        self.compute_dtype = dtype
+        self.embracenet.compute_dtype = dtype
+        return self
+
+    def set_rng(self, mode, generator=None, seed=None, row0=None):
+        _RngMixin.set_rng(self, mode, generator, seed, row0)
+        self.embracenet.set_rng(mode, generator, self.rng_seed, self.rng_row0)
+        return self
+
+    # -- forward ------------------------------------------------------------------------------------
+    def _post_forward(self, y, rng, T):
+        mods = list(self.post)
+        i, layer_id = 0, 0
+        while i < len(mods):
+            lin = mods[i]
+            relu = i + 1 < len(mods) and isinstance(mods[i + 1], nn.ReLU)
+            p = 0.0
+            if relu and i + 2 < len(mods) and isinstance(mods[i + 2], nn.Dropout):
+                p = float(mods[i + 2].p) if self.training else 0.0
+            y = F_.linear(y, lin.weight, lin.bias, relu=relu, dropout_p=p, layer_id=layer_id, rng=rng, compute_dtype=T)
+            i += 3 if relu else 1
+            layer_id += 1
+        return y
+
+    def forward(self, x, availabilities=None, selection_probabilities=None, is_training=False,
+                embracenet_dropout=True):
+        x_FFNN, x_CNN = x
+        dev = x_FFNN.device
+        T = self.compute_dtype or self.embracenet.docking_0.weight.dtype
+        if T == torch.bfloat16:
+            with torch.autocast("cuda", dtype=torch.bfloat16):
+                h0, h1 = self.FFNN(x_FFNN), self.CNN(x_CNN)
+        else:
+            h0, h1 = self.FFNN(x_FFNN), self.CNN(x_CNN)
+        B = h0.shape[0]
+
+        self.embracenet.rng_mode, self.embracenet.generator = self.rng_mode, self.generator
+        self.embracenet.rng_seed, self.embracenet.rng_row0 = self.rng_seed, self.rng_row0
+        device_dropout = False
+        if is_training and embracenet_dropout:                              # :178-182
+            if self.rng_mode == "host":
+                r = torch.rand(1, generator=self.generator)[0]
+                if r >= 0.5:
+                    t = torch.round(torch.rand([B], generator=self.generator)).to(torch.int64)
+                    availabilities = nn.functional.one_hot(t, num_classes=2).float()
+            else:
+                device_dropout = True
+        # the reference ignores the selection_probabilities argument and always uses its own (:184-187)
+        sp = self.selection_probabilities
+        key = (sp.data_ptr(), sp._version, dev)
+        if getattr(self, "_sel_key", None) != key:      # device copy made once, not per step (no H2D in a graph)
+            self._sel_dev, self._sel_key = sp.detach().to(device=dev, dtype=torch.float32).view(1, 2), key
+        p = self._sel_dev
+        E = self.embracenet([h0, h1], availabilities=availabilities, selection_probabilities=p,
+                            _device_dropout=device_dropout, _advance=False)
+        rng = self.embracenet._rng_state(dev)
+        out = self._post_forward(E, rng, T)
+        self.embracenet._advance_step()
+        return out

@@ -1,0 +1,196 @@
+"""autograd bindings of the HIP kernels (one C-ABI call per forward, one per backward).
+
+Everything here only enqueues work on torch's current HIP stream; nothing synchronises, so a whole
+train step built from these functions can be captured into a hipGraph (torch.cuda.CUDAGraph).
+"""
+import torch
+
+from . import _lib
+from ._lib import DTYPE_CODE, PARAM_DTYPE, check, ptr, stream
+
+
+class RngState:
+    """Perf-mode RNG coordinates handed to the kernels (include/embrace_hip.h, "RNG contract").
+
+    seed      Philox key
+    step_val  host-side part of the step counter
+    step_dev  optional uint64 device scalar added to step_val (advances under graph replay)
+    row0      global index of local row 0 (data-parallel shard offset)
+    """
+    __slots__ = ("seed", "step_val", "step_dev", "row0")
+
+    def __init__(self, seed=0, step_val=0, step_dev=None, row0=0):
+        self.seed, self.step_val, self.step_dev, self.row0 = int(seed), int(step_val), step_dev, int(row0)
+
+
+def _as(t, dtype):
+    t = t if t.dtype == dtype else t.to(dtype)
+    return t if t.is_contiguous() else t.contiguous()
+
+
+def select_prep(p, avail, B, rng=None, device_dropout=False, status=None):
+    """EmbraceNetMultimodal.py:63-76,178-184 + torch.multinomial's cdf -> cdf0[B] (fp32, device)."""
+    _lib.require_cuda(p, avail)
+    p = _as(p, torch.float32)
+    if p.dim() == 1:
+        p = p.view(1, -1)
+    if p.shape[-1] != 2:
+        raise NotImplementedError("the HIP path implements the two-modality EmbraceNet (epigenomic + sequence)")
+    if avail is not None:
+        avail = _as(avail, torch.float32)
+    rng = rng or RngState()
+    cdf0 = torch.empty(B, dtype=torch.float32, device=p.device)
+    if status is None:
+        status = torch.zeros(1, dtype=torch.int32, device=p.device)
+    check(_lib.lib().emb_select_prep(ptr(p), p.shape[0], ptr(avail), int(bool(device_dropout)), rng.seed, rng.step_val,
+                                     ptr(rng.step_dev), rng.row0, ptr(cdf0), ptr(status), B, stream()),
+          "emb_select_prep")
+    return cdf0, status
+
+
+class _EmbraceFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x0, x1, w0, b0, w1, b1, cdf0, u, rng, compute_dtype):
+        _lib.require_cuda(x0, x1, w0, w1)
+        T = compute_dtype
+        P = PARAM_DTYPE[T]
+        B, d0 = x0.shape
+        d1 = x1.shape[1]
+        c = w0.shape[0]
+        x0c, x1c = _as(x0, T), _as(x1, T)
+        w0c, w1c = _as(w0.detach(), T), _as(w1.detach(), T)
+        b0c, b1c = _as(b0.detach(), P), _as(b1.detach(), P)
+        E = torch.empty(B, c, dtype=T, device=x0.device)
+        code = torch.empty(B, c, dtype=torch.uint8, device=x0.device)
+        if u is not None:
+            u = _as(u, torch.float64)
+            assert u.shape == (B, c)
+        check(_lib.lib().emb_embrace_fwd(ptr(x0c), ptr(x1c), ptr(w0c), ptr(b0c), ptr(w1c), ptr(b1c), ptr(cdf0), ptr(u),
+                                         rng.seed, rng.step_val, ptr(rng.step_dev), rng.row0, ptr(E), ptr(code),
+                                         B, d0, d1, c, DTYPE_CODE[T], stream()), "emb_embrace_fwd")
+        ctx.save_for_backward(x0c, x1c, w0c, w1c, code)
+        ctx.T = T
+        ctx.in_dtypes = (x0.dtype, x1.dtype, w0.dtype, b0.dtype, w1.dtype, b1.dtype)
+        ctx.mark_non_differentiable(code)
+        return E, code
+
+    @staticmethod
+    def backward(ctx, dE, _dcode):
+        x0c, x1c, w0c, w1c, code = ctx.saved_tensors
+        T = ctx.T
+        P = PARAM_DTYPE[T]
+        B, d0 = x0c.shape
+        d1 = x1c.shape[1]
+        c = w0c.shape[0]
+        dev = x0c.device
+        dE = _as(dE, T)
+        need0, need1 = ctx.needs_input_grad[0], ctx.needs_input_grad[1]
+        dX0 = torch.empty(B, d0, dtype=T, device=dev) if need0 else None
+        dX1 = torch.empty(B, d1, dtype=T, device=dev) if need1 else None
+        dW0 = torch.empty(c, d0, dtype=P, device=dev)
+        dW1 = torch.empty(c, d1, dtype=P, device=dev)
+        db0 = torch.empty(c, dtype=P, device=dev)
+        db1 = torch.empty(c, dtype=P, device=dev)
+        check(_lib.lib().emb_embrace_bwd(ptr(dE), ptr(code), ptr(x0c), ptr(x1c), ptr(w0c), ptr(w1c), ptr(dX0), ptr(dX1),
+                                         ptr(dW0), ptr(db0), ptr(dW1), ptr(db1), B, d0, d1, c, DTYPE_CODE[T], stream()),
+              "emb_embrace_bwd")
+        t = ctx.in_dtypes
+        cast = lambda g, d: None if g is None else (g if g.dtype == d else g.to(d))
+        return (cast(dX0, t[0]), cast(dX1, t[1]), cast(dW0, t[2]), cast(db0, t[3]), cast(dW1, t[4]), cast(db1, t[5]),
+                None, None, None, None)
+
+
+def embrace(x0, x1, w0, b0, w1, b1, cdf0, u=None, rng=None, compute_dtype=None):
+    """Fused docking + ReLU + modality selection (EmbraceNetMultimodal.py:52-60, 80-88).
+    returns (E [B,c], code [B,c] uint8 with bit0 = selected modality)."""
+    compute_dtype = compute_dtype or x0.dtype
+    return _EmbraceFn.apply(x0, x1, w0, b0, w1, b1, cdf0, u, rng or RngState(), compute_dtype)
+
+
+class _LinearFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, w, b, relu, dropout_p, layer_id, rng, compute_dtype):
+        _lib.require_cuda(x, w, b)
+        T = compute_dtype
+        P = PARAM_DTYPE[T]
+        B, K = x.shape
+        N = w.shape[0]
+        xc, wc, bc = _as(x, T), _as(w.detach(), T), _as(b.detach(), P)
+        y = torch.empty(B, N, dtype=T, device=x.device)
+        need_mask = bool(relu) or dropout_p > 0
+        mask = torch.empty(B, N, dtype=torch.uint8, device=x.device) if need_mask else None
+        check(_lib.lib().emb_linear_fwd(ptr(xc), ptr(wc), ptr(bc), ptr(y), ptr(mask), int(bool(relu)), float(dropout_p),
+                                        int(layer_id), rng.seed, rng.step_val, ptr(rng.step_dev), rng.row0, B, K, N,
+                                        DTYPE_CODE[T], stream()), "emb_linear_fwd")
+        ctx.save_for_backward(xc, wc, mask)
+        ctx.cfg = (T, bool(relu), float(dropout_p), x.dtype, w.dtype, b.dtype)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        xc, wc, mask = ctx.saved_tensors
+        T, relu, dropout_p, tx, tw, tb = ctx.cfg
+        P = PARAM_DTYPE[T]
+        B, K = xc.shape
+        N = wc.shape[0]
+        dy = _as(dy, T)
+        dx = torch.empty(B, K, dtype=T, device=xc.device) if ctx.needs_input_grad[0] else None
+        dw = torch.empty(N, K, dtype=P, device=xc.device)
+        db = torch.empty(N, dtype=P, device=xc.device)
+        check(_lib.lib().emb_linear_bwd(ptr(dy), ptr(mask), ptr(xc), ptr(wc), ptr(dx), ptr(dw), ptr(db), int(relu),
+                                        dropout_p, B, K, N, DTYPE_CODE[T], stream()), "emb_linear_bwd")
+        cast = lambda g, d: None if g is None else (g if g.dtype == d else g.to(d))
+        return cast(dx, tx), cast(dw, tw), cast(db, tb), None, None, None, None, None
+
+
+def linear(x, w, b, relu=False, dropout_p=0.0, layer_id=0, rng=None, compute_dtype=None):
+    """dropout(relu(x w^T + b)) with the epilogue fused (EmbraceNetMultimodal.py:143-151)."""
+    return _LinearFn.apply(x, w, b, relu, dropout_p, layer_id, rng or RngState(), compute_dtype or x.dtype)
+
+
+class _WeightedCEFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, logits, target, class_counts, global_counts, confusion):
+        _lib.require_cuda(logits, target)
+        T = logits.dtype
+        z = logits if logits.is_contiguous() else logits.contiguous()
+        tgt = _as(target.reshape(-1), torch.int64)
+        B = z.shape[0]
+        if z.shape[1] != 2:
+            raise NotImplementedError("weighted CE kernel implements the reference's 2-class task")
+        loss = torch.empty(1, dtype=torch.float32, device=z.device)
+        dz = torch.empty_like(z)
+        check(_lib.lib().emb_weighted_ce(ptr(z), ptr(tgt), ptr(class_counts), int(bool(global_counts)), ptr(loss), ptr(dz),
+                                         ptr(confusion), B, DTYPE_CODE[T], stream()), "emb_weighted_ce")
+        ctx.save_for_backward(dz)
+        return loss.view(())
+
+    @staticmethod
+    def backward(ctx, g):
+        (dz,) = ctx.saved_tensors
+        return dz * g.to(dz.dtype), None, None, None, None
+
+
+def weighted_ce(logits, target, class_counts=None, global_counts=False, confusion=None):
+    """Per-batch class-weighted 2-class cross-entropy of the reference's train/eval step
+    (utils/utils.py:121-140, training_models_multimodal.py:140-141,151-154), loss in fp32.
+    class_counts: int64[2] device tensor; written (pos, n) unless global_counts (then read).
+    confusion: optional int64[4] device accumulator (TP, predicted-positive, positive, n)."""
+    if class_counts is None:
+        class_counts = torch.empty(2, dtype=torch.int64, device=logits.device)
+    return _WeightedCEFn.apply(logits, target, class_counts, global_counts, confusion)
+
+
+def count_labels(target, out=None):
+    tgt = _as(target.reshape(-1), torch.int64)
+    _lib.require_cuda(tgt)
+    out = out if out is not None else torch.empty(2, dtype=torch.int64, device=tgt.device)
+    check(_lib.lib().emb_count_labels(ptr(tgt), ptr(out), tgt.numel(), stream()), "emb_count_labels")
+    return out
+
+
+def cast(src, dtype, out=None):
+    src = src if src.is_contiguous() else src.contiguous()
+    out = out if out is not None else torch.empty(src.shape, dtype=dtype, device=src.device)
+    check(_lib.lib().emb_cast(ptr(src), DTYPE_CODE[src.dtype], ptr(out), DTYPE_CODE[dtype], src.numel(), stream()), "emb_cast")
+    return out

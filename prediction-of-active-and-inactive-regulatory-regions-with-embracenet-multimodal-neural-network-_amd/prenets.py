@@ -1,0 +1,62 @@
+"""Per-modality pre-networks feeding the EmbraceNet docking layers.
+
+Interface mirrors the reference (same constructor arguments, same Optuna parameter names asked in the
+same order, same ``output_size`` attribute and the same state-dict keys ``model.{3i}.*`` /
+``CNN_model.{5i}.*``) so checkpoints and the harness keep working:
+  FFNN_pre  <- BIOINF_tesi/models/FFNN_pre.py:10-49   epigenomic features  [B,F]     -> [B,d0]
+  CNN_pre   <- BIOINF_tesi/models/CNN_pre.py:10-76    one-hot DNA window   [B,4,256] -> [B,d1]
+
+SURVEY 8(f1): these are "next" rows.  In this round they run on stock PyTorch-ROCm operators
+(hipBLASLt / MIOpen); the hand-written HIP path starts at the docking layers.
+"""
+import torch.nn as nn
+
+_FFNN_UNITS = ([32, 64, 128, 256], [16, 32, 64, 128], [4, 16, 32, 64], [4, 16, 32])
+_CNN_CHANNELS = ([16, 32, 64], [32, 64, 96], [64, 96, 128, 256], [128, 256, 512])
+
+
+def conv_output_length(length, kernel, padding, stride):
+    """utils/utils.py:143-153"""
+    return int(((length + 2 * padding - kernel) / stride) + 1)
+
+
+class FFNN_pre(nn.Module):
+    def __init__(self, trial, in_features, device, classes=2):
+        super().__init__()
+        self.trial, self.classes, self.device = trial, classes, device
+        n_layers = trial.suggest_int("FFNN_n_layers", 1, 4)
+        stack, width = [], in_features
+        for i in range(n_layers):
+            out = trial.suggest_categorical(f"FFNN_n_units_l{i}", _FFNN_UNITS[i])
+            p = trial.suggest_categorical(f"FFNN_dropout_l{i}", [0.0, 0.2, 0.3, 0.4] if i < 2 else [0.0, 0.4, 0.5])
+            stack += [nn.Linear(width, out), nn.ReLU(), nn.Dropout(p)]
+            width = out
+        self.output_size = width
+        self.model = nn.Sequential(*stack)
+
+    def forward(self, x):
+        return self.model(x)
+
+
+class CNN_pre(nn.Module):
+    def __init__(self, trial, device):
+        super().__init__()
+        self.trial, self.device = trial, device
+        n_layers = trial.suggest_int("CNN_n_layers", 1, 4)
+        stack, channels, length = [], 4, 256
+        for i in range(n_layers):
+            out = trial.suggest_categorical(f"CNN_out_channels_l{i}", _CNN_CHANNELS[i])
+            k = trial.suggest_categorical(f"CNN_kernel_size_l{i}", [5, 11, 15])
+            pad = int((k - 1) / 2)
+            stack += [nn.Conv1d(channels, out, kernel_size=k, stride=1, padding=pad), nn.BatchNorm1d(out), nn.ReLU(),
+                      nn.MaxPool1d(kernel_size=10, stride=2)]
+            p = trial.suggest_categorical(f"CNN_dropout_l{i}", [0, 0.2, 0.3, 0.4] if i < 1 else [0, 0.4, 0.5])
+            stack.append(nn.Dropout(p))
+            channels = out
+            length = conv_output_length(conv_output_length(length, k, pad, 1), 10, 0, 2)
+        self.output_size = channels * length
+        self.CNN_model = nn.Sequential(*stack)
+
+    def forward(self, x):
+        y = self.CNN_model(x)
+        return y.reshape(y.size(0), -1)

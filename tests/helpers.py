@@ -1,0 +1,55 @@
+"""Shared test helpers: golden-fixture access and regeneration of the inputs the fixtures were made from."""
+import json
+import os
+
+import numpy as np
+
+from oracle import datagen as dg
+
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+class Golden:
+    def __init__(self, name):
+        z = np.load(os.path.join(GOLDEN, name + ".npz"), allow_pickle=False)
+        self.arrays = {k: z[k] for k in z.files if k != "__meta__"}
+        self.meta = json.loads(bytes(z["__meta__"]).decode())
+
+    def __getitem__(self, k):
+        return self.arrays[k]
+
+
+def unpack_idx(packed, B, c):
+    return np.unpackbits(packed)[: B * c].reshape(B, c).astype(np.int64)
+
+
+def g1_inputs(case):
+    """Inputs of a G1 case, regenerated exactly as tests/golden/make_golden.py did."""
+    name, B, d0, d1, c = case["case"], case["B"], case["d0"], case["d1"], case["c"]
+    X = [dg.uniform(name + "/x0", (B, d0)), dg.uniform(name + "/x1", (B, d1))]
+    W = [dg.weight(name + "/w0", (c, d0), d0), dg.weight(name + "/w1", (c, d1), d1)]
+    b = [dg.weight(name + "/b0", (c,), d0), dg.weight(name + "/b1", (c,), d1)]
+    avail = None
+    if case["avail"] == "onehot":
+        avail = np.eye(2, dtype=np.float32)[dg.integers(name + "/avail_t", (B,), 2)]
+    elif case["avail"] == "mixed":
+        avail = np.array([[1, 1], [1, 0], [0, 1]], dtype=np.float32)[dg.integers(name + "/avail_t", (B,), 3)]
+    p = None if case["p"] == "none" else dg.uniform(name + "/p", (B, 2), 0.05, 1.0).astype(np.float32)
+    return X, W, b, avail, p
+
+
+def model_fill(tag):
+    """Parameter filler used for G2/G3/G9 models (same rule as make_golden.build_ref_model)."""
+    def fill(key, shape):
+        fan = int(np.prod(shape[1:])) if len(shape) > 1 else max(int(shape[0]), 1)
+        if key.endswith(".bias") or (len(shape) == 1):
+            if ".CNN_model." in key and key.split(".")[2] != "0" and int(key.split(".")[2]) % 5 == 1:
+                return dg.uniform(f"{tag}/{key}", shape, 0.5, 1.5) if key.endswith("weight") \
+                    else dg.uniform(f"{tag}/{key}", shape, -0.2, 0.2)
+            return dg.weight(f"{tag}/{key}", shape, 16)
+        return dg.weight(f"{tag}/{key}", shape, fan)
+    return fill
+
+
+def model_batch(tag, B, F_in, pos_rate=0.1):
+    return (dg.features(tag + "/x1", B, F_in), dg.onehot_sequence(tag + "/x2", B), dg.labels(tag + "/y", B, pos_rate))

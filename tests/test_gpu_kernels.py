@@ -1,0 +1,318 @@
+"""GPU parity tests of the HIP kernels, called through the C ABI (ctypes) -- `pytest -m gpu`.
+
+Oracle = oracle/embrace_oracle.py (numpy restatement of the reference, pinned to the imported reference by
+tests/golden/*).  Tolerances: idx / code / counts bit-exact; fp64 kernels 1e-11; fp32 kernels 1e-5 absolute on
+O(1) values (north-star bar: forward logits within 1e-5); bf16 kernels are compared with the oracle fed the
+same bf16-rounded operands, tolerance 2e-2 relative to the output scale (bf16 output rounding = 2^-8).
+"""
+import numpy as np
+import pytest
+import torch
+
+from helpers import Golden, g1_inputs, unpack_idx
+from oracle import datagen as dg
+from oracle import embrace_oracle as orc
+
+pytestmark = pytest.mark.gpu
+
+DEV = "cuda"
+TD = {"f64": torch.float64, "f32": torch.float32, "bf16": torch.bfloat16}
+TOL = {"f64": 1e-11, "f32": 1e-5, "bf16": 2e-2}
+
+
+def dev(a, dtype=None):
+    t = torch.from_numpy(np.ascontiguousarray(a))
+    if dtype is not None:
+        t = t.to(dtype)
+    return t.to(DEV)
+
+
+def host(t):
+    return t.detach().double().cpu().numpy()
+
+
+def round_to(a, dt):
+    """operand as the kernel sees it after the cast to its storage type"""
+    return torch.from_numpy(np.asarray(a, dtype=np.float64)).to(TD[dt]).double().numpy()
+
+
+# ------------------------------------------------------------------------------------------ G1
+def _g1_cases():
+    g = Golden("G1_embracenet_forward")
+    return g, g.meta["cases"]
+
+
+@pytest.mark.parametrize("i", range(27))
+def test_g1_embracenet_forward_matches_reference(ea, i):
+    g, cases = _g1_cases()
+    case = cases[i]
+    X, W, b, avail, p = g1_inputs(case)
+    B, c, dt = case["B"], case["c"], case["dtype"]
+    T = TD[dt]
+    net = ea.EmbraceNet(DEV, [case["d0"], case["d1"]], c).to(DEV).to(T)
+    with torch.no_grad():
+        for m in range(2):
+            getattr(net, f"docking_{m}").weight.copy_(dev(W[m], T))
+            getattr(net, f"docking_{m}").bias.copy_(dev(b[m], T))
+    net.set_rng("host")
+    torch.manual_seed(case["seed"])            # same CPU generator state the reference started from
+    out = net([dev(X[0], T), dev(X[1], T)], availabilities=None if avail is None else dev(avail),
+              selection_probabilities=None if p is None else dev(p))
+    idx_ref = unpack_idx(g[case["key"] + "_idx"], B, c)
+    assert np.array_equal(net.modality_indices().cpu().numpy(), idx_ref), "multinomial index tensor not bit-exact"
+    ref = g[case["key"] + "_out"].astype(np.float64)
+    err = np.abs(host(out) - ref).max()
+    assert err < (1e-5 if dt == "f32" else (1e-11 if ref.dtype == np.float64 and B * c <= 4096 else 1e-6)), err
+    if dt == "f64":   # large f64 cases are stored as f32: compare fingerprints at full precision
+        chk = dg.checksum(host(out))
+        assert abs(chk["sum"] - case["out_chk"]["sum"]) < 1e-8 * max(1.0, case["out_chk"]["abs"])
+        assert abs(chk["dot"] - case["out_chk"]["dot"]) < 1e-8 * max(1.0, case["out_chk"]["abs"])
+
+
+# ------------------------------------------------------------------------- fwd/bwd vs numpy oracle
+SHAPES = [(8, 4, 64, 32), (64, 16, 1856, 512), (100, 32, 1024, 768), (37, 5, 70, 30), (256, 64, 2048, 256),
+          (1024, 16, 1856, 256), (3, 256, 96, 1024)]
+
+
+@pytest.mark.parametrize("dt", ["f64", "f32", "bf16"])
+@pytest.mark.parametrize("shape", SHAPES)
+def test_embrace_forward_backward_vs_oracle(ea, shape, dt):
+    B, d0, d1, c = shape
+    if dt == "f64" and B * c * d1 > 64 * 512 * 1856 * 2:
+        pytest.skip("fp64 oracle case kept small")
+    T = TD[dt]
+    name = f"fb/{B}_{d0}_{d1}_{c}"
+    X = [round_to(dg.uniform(name + "/x0", (B, d0)), dt), round_to(dg.uniform(name + "/x1", (B, d1)), dt)]
+    W = [round_to(dg.weight(name + "/w0", (c, d0), d0), dt), round_to(dg.weight(name + "/w1", (c, d1), d1), dt)]
+    pd = "f64" if dt == "f64" else "f32"
+    b = [round_to(dg.weight(name + "/b0", (c,), d0), pd), round_to(dg.weight(name + "/b1", (c,), d1), pd)]
+    p = dg.uniform(name + "/p", (B, 2), 0.05, 1.0).astype(np.float32)
+    u = dg.uniform(name + "/u", (B, c))
+    dE = round_to(dg.uniform(name + "/dE", (B, c), -1, 1), dt)
+    cdf = orc.selection_cdf(p)
+    idx = orc.embrace_indices(cdf, u)
+    E, Z = orc.embrace_forward(X, W, b, idx)
+    dX, dW, db = orc.embrace_backward(dE, X, W, Z, idx)
+
+    F = ea.functional
+    P = torch.float64 if dt == "f64" else torch.float32
+    x0, x1 = dev(X[0], T).requires_grad_(), dev(X[1], T).requires_grad_()
+    w0, w1 = dev(W[0], P).requires_grad_(), dev(W[1], P).requires_grad_()
+    b0, b1 = dev(b[0], P).requires_grad_(), dev(b[1], P).requires_grad_()
+    cdf0, status = F.select_prep(dev(p), None, B)
+    assert int(status.item()) == 0
+    assert np.array_equal(cdf0.cpu().numpy().view(np.uint32), cdf[:, 0].view(np.uint32)), "cdf0 not bit-exact"
+    Eg, code = F.embrace(x0, x1, w0, b0, w1, b1, cdf0, u=dev(u), compute_dtype=T)
+    code = code.cpu().numpy()
+    assert np.array_equal(code & 1, idx), "index tensor not bit-exact"
+    scale = max(1.0, np.abs(E).max())
+    err = np.abs(host(Eg) - E).max() / scale
+    assert err < TOL[dt], ("forward", err)
+    # relu-active bit: may legitimately differ only where |pre| is at rounding level
+    pre = np.where(idx == 1, Z[1], Z[0])
+    flip = ((code >> 1) & 1) != (pre > 0)
+    assert np.all(np.abs(pre[flip]) < TOL[dt] * scale)
+    Eg.backward(dev(dE, T))
+    for name_, got, want in (("dX0", x0.grad, dX[0]), ("dX1", x1.grad, dX[1]), ("dW0", w0.grad, dW[0]),
+                             ("dW1", w1.grad, dW[1]), ("db0", b0.grad, db[0]), ("db1", b1.grad, db[1])):
+        s = max(1.0, np.abs(want).max())
+        e = np.abs(host(got) - want).max() / s
+        # elements whose ReLU decision flipped at rounding level would perturb grads: none expected here
+        assert e < (TOL[dt] * (4 if dt == "bf16" else 10)), (name_, e)
+
+
+def test_forward_is_deterministic_and_code_consistent(ea):
+    B, d0, d1, c = 128, 16, 1856, 512
+    F = ea.functional
+    g = torch.Generator(device="cpu").manual_seed(5)
+    x0, x1 = torch.rand(B, d0, generator=g).to(DEV), torch.rand(B, d1, generator=g).to(DEV)
+    w0, w1 = (torch.rand(c, d0, generator=g) - 0.5).to(DEV), ((torch.rand(c, d1, generator=g) - 0.5) * 0.05).to(DEV)
+    b0, b1 = torch.zeros(c, device=DEV), torch.zeros(c, device=DEV)
+    cdf0, _ = F.select_prep(torch.tensor([[0.3, 0.7]], device=DEV), None, B)
+    rng = F.RngState(seed=1234, step_val=7)
+    outs = [F.embrace(x0, x1, w0, b0, w1, b1, cdf0, rng=rng) for _ in range(3)]
+    for E, code in outs[1:]:
+        assert torch.equal(E, outs[0][0]) and torch.equal(code, outs[0][1])
+    E, code = outs[0]
+    assert torch.equal((E > 0), ((code >> 1) & 1).bool())
+
+
+# ------------------------------------------------------------------------------------------ G4
+def test_g4_rng_contract_host_replay(ea):
+    g = Golden("G4_rng_contract")
+    F = ea.functional
+    for case in g.meta["cases"]:
+        seed, B, c, p0 = case["seed"], case["B"], case["c"], case["p0"]
+        torch.manual_seed(seed)
+        r1, rB = torch.rand(1), torch.rand([B])
+        assert np.array_equal(r1.numpy().view(np.uint32), g[case["key"] + "_r1_bits"])
+        assert np.array_equal(rB.numpy().view(np.uint32), g[case["key"] + "_rB_bits"])
+        u = torch.rand(B * c, dtype=torch.float64)
+        assert np.array_equal(u[:64].numpy().view(np.uint64), g[case["key"] + "_u_bits"])
+        p = torch.tensor([[p0, 1 - p0]], dtype=torch.float32)
+        cdf0, _ = F.select_prep(p.to(DEV), None, B)
+        assert int(cdf0[0].cpu().numpy().view(np.uint32)) == case["cdf0_bits"]
+        z = torch.zeros(B, 8, device=DEV)
+        w = torch.zeros(c, 8, device=DEV)
+        bz = torch.zeros(c, device=DEV)
+        _, code = F.embrace(z, z, w, bz, w, bz, cdf0, u=u.view(B, c).to(DEV))
+        assert np.array_equal((code & 1).cpu().numpy(), unpack_idx(g[case["key"] + "_idx"], B, c))
+
+
+def test_philox_mode_matches_oracle_and_is_shard_invariant(ea):
+    F = ea.functional
+    B, c, seed, step = 96, 200, 0xDEADBEEFCAFE, 11
+    p = torch.tensor([[0.37, 0.63]], device=DEV)
+    z = torch.zeros(B, 4, device=DEV)
+    w = torch.zeros(c, 4, device=DEV)
+    bz = torch.zeros(c, device=DEV)
+    cdf0, _ = F.select_prep(p, None, B)
+    _, code = F.embrace(z, z, w, bz, w, bz, cdf0, rng=F.RngState(seed, step))
+    idx = (code & 1).cpu().numpy()
+    u = orc.philox_uniform53(seed, (step << 8) | 0, np.arange(B * c, dtype=np.uint64)).reshape(B, c)
+    want = orc.embrace_indices(orc.selection_cdf(p.cpu().numpy()), u)
+    assert np.array_equal(idx, want)
+    # two "ranks" of 48 rows each reproduce the single-process result (row0 = global row offset)
+    step_dev = torch.tensor([5], dtype=torch.int64, device=DEV)
+    halves = []
+    for r in range(2):
+        _, cd = F.embrace(z[:48], z[:48], w, bz, w, bz, cdf0[:48].contiguous(), rng=F.RngState(seed, step - 5, step_dev, row0=48 * r))
+        halves.append((cd & 1).cpu().numpy())
+    assert np.array_equal(np.concatenate(halves), want)
+
+
+def test_device_modality_dropout_matches_oracle(ea):
+    F = ea.functional
+    B, seed = 300, 99
+    p = torch.tensor([[0.6, 0.4]], device=DEV)
+    seen = set()
+    for step in range(12):
+        cdf0, status = F.select_prep(p, None, B, rng=F.RngState(seed, step, row0=1000), device_dropout=True)
+        gate = orc.philox_uniform24(seed, (step << 8) | 1, np.zeros(1, np.uint64))[0]
+        if gate >= 0.5:
+            t = orc.philox_uniform24(seed, (step << 8) | 2, np.arange(1000, 1000 + B, dtype=np.uint64)) > 0.5
+            avail = np.stack([~t, t], 1).astype(np.float32)
+        else:
+            avail = None
+        want = orc.selection_cdf(p.cpu().numpy(), avail if avail is not None else np.ones((B, 2), np.float32))
+        assert np.array_equal(cdf0.cpu().numpy(), want[:, 0])
+        seen.add(bool(gate >= 0.5))
+    assert seen == {True, False}
+
+
+def test_invalid_distribution_raises_like_reference(ea):
+    g = Golden("G8_error_cases")
+    assert {c["name"] for c in g.meta["cases"]} == {"modality_count", "zero_distribution"}
+    net = ea.EmbraceNet(DEV, [4, 8], 16).to(DEV).double().set_rng("host")
+    with pytest.raises(AssertionError):
+        net([torch.zeros(2, 4, dtype=torch.float64, device=DEV)])
+    with pytest.raises(RuntimeError, match="invalid multinomial distribution"):
+        net([torch.zeros(2, 4, dtype=torch.float64, device=DEV), torch.zeros(2, 8, dtype=torch.float64, device=DEV)],
+            availabilities=torch.tensor([[1.0, 0.0], [0.0, 1.0]]), selection_probabilities=torch.tensor([[0.0, 1.0], [0.0, 1.0]]))
+
+
+# -------------------------------------------------------------------------------------- linear
+@pytest.mark.parametrize("dt", ["f64", "f32", "bf16"])
+@pytest.mark.parametrize("shape", [(64, 512, 128, True), (100, 768, 64, True), (37, 30, 2, False), (1024, 256, 32, True),
+                                   (64, 128, 2, False), (256, 1024, 512, True)])
+def test_linear_forward_backward_vs_oracle(ea, shape, dt):
+    B, K, N, relu = shape
+    T = TD[dt]
+    P = torch.float64 if dt == "f64" else torch.float32
+    name = f"lin/{B}_{K}_{N}"
+    x = round_to(dg.uniform(name + "/x", (B, K)), dt)
+    w = round_to(dg.weight(name + "/w", (N, K), K), dt)
+    b = round_to(dg.weight(name + "/b", (N,), K), "f64" if dt == "f64" else "f32")
+    dy = round_to(dg.uniform(name + "/dy", (B, N), -1, 1), dt)
+    y, z = orc.linear_forward(x, w, b, relu)
+    dx, dw, db = orc.linear_backward(dy, x, w, z, relu)
+    F = ea.functional
+    xg, wg, bg = dev(x, T).requires_grad_(), dev(w, P).requires_grad_(), dev(b, P).requires_grad_()
+    yg = F.linear(xg, wg, bg, relu=relu, compute_dtype=T)
+    s = max(1.0, np.abs(y).max())
+    assert np.abs(host(yg) - y).max() / s < TOL[dt]
+    yg.backward(dev(dy, T))
+    for nm, got, want in (("dx", xg.grad, dx), ("dw", wg.grad, dw), ("db", bg.grad, db)):
+        s = max(1.0, np.abs(want).max())
+        assert np.abs(host(got) - want).max() / s < TOL[dt] * (4 if dt == "bf16" else 10), nm
+
+
+def test_linear_dropout_mask_is_philox_and_scaled(ea):
+    F = ea.functional
+    B, K, N, p, seed, step, layer = 64, 96, 128, 0.3, 77, 3, 1
+    x = dev(dg.uniform("ld/x", (B, K)), torch.float32).requires_grad_()
+    w = dev(dg.weight("ld/w", (N, K), K), torch.float32)
+    b = dev(dg.weight("ld/b", (N,), K), torch.float32)
+    y = F.linear(x, w, b, relu=True, dropout_p=p, layer_id=layer, rng=F.RngState(seed, step, row0=10))
+    y0 = F.linear(x, w, b, relu=True)
+    r = orc.philox_uniform24(seed, (step << 8) | (16 + layer), (np.arange(B * N, dtype=np.uint64) + np.uint64(10 * N))).reshape(B, N)
+    keep = r >= np.float32(p)
+    want = np.where(keep, host(y0) / (1 - p), 0.0)
+    assert np.abs(host(y) - want).max() < 1e-5
+    assert 0.6 < keep.mean() < 0.8
+    y.sum().backward()
+    gx = host(x.grad)
+    m = keep & (host(y0) > 0)
+    want_gx = (m / (1 - p)) @ host(w)
+    assert np.abs(gx - want_gx).max() < 1e-4
+
+
+# ------------------------------------------------------------------------------------ loss / metrics
+def test_g5_weighted_ce_known_answers(ea):
+    g = Golden("G5_weighted_ce")
+    F = ea.functional
+    for case in g.meta["cases"]:
+        i, B, rate = case["i"], case["B"], case["rate"]
+        y = dg.labels(f"g5/{i}/y", B, rate) if 0 < rate < 1 else np.full((B, 1), int(rate), dtype=np.int64)
+        z = dg.uniform(f"g5/{i}/z", (B, 2), -3, 3)
+        for T, tol in ((torch.float64, 2e-6), (torch.float32, 2e-6)):
+            zg = dev(z, T).requires_grad_()
+            counts = torch.zeros(2, dtype=torch.int64, device=DEV)
+            conf = torch.zeros(4, dtype=torch.int64, device=DEV)
+            loss = F.weighted_ce(zg, dev(y), class_counts=counts, confusion=conf)
+            assert abs(loss.item() - case["loss"]) < tol, (i, loss.item(), case["loss"])
+            loss.backward()
+            assert np.abs(host(zg.grad) - g[f"c{i}_dz"]).max() < tol
+            assert counts.tolist() == [case["pos"], B]
+            tp, pp, pos, n = orc.confusion_counts(z, y)
+            assert conf.tolist() == [tp, pp, pos, n]
+
+
+def test_weighted_ce_global_counts_sum_to_single_process(ea):
+    """DP contract: with (pos, n) of the GLOBAL batch supplied, shard losses and gradients add up to the
+    single-process result (SURVEY 8e coupling 1)."""
+    F = ea.functional
+    B = 96
+    y = dg.labels("gc/y", B, 0.25)
+    z = dg.uniform("gc/z", (B, 2), -2, 2)
+    zg = dev(z, torch.float32).requires_grad_()
+    full = F.weighted_ce(zg, dev(y))
+    full.backward()
+    counts = F.count_labels(dev(y))
+    tot, grads = 0.0, []
+    for s in (slice(0, 40), slice(40, 96)):
+        zs = dev(z[s], torch.float32).requires_grad_()
+        l = F.weighted_ce(zs, dev(y[s]), class_counts=counts, global_counts=True)
+        l.backward()
+        tot += l.item()
+        grads.append(host(zs.grad))
+    assert abs(tot - full.item()) < 1e-6
+    assert np.abs(np.concatenate(grads) - host(zg.grad)).max() < 1e-7
+
+
+# -------------------------------------------------------------------------------------- optimizers
+def test_g7_optimizer_steps(ea):
+    g = Golden("G7_optimizer_steps")
+    from embracenet_amd import optim
+    for case in g.meta["cases"]:
+        name = case["name"]
+        for T, tol in ((torch.float64, 1e-13), (torch.float32, 2e-6)):
+            p = torch.nn.Parameter(dev(dg.uniform(f"g7/{name}/p", (257,), -1, 1), T))
+            cls = optim.Adam if name == "adam" else optim.RMSprop
+            opt = cls([p], lr=case["lr"], weight_decay=case["weight_decay"])
+            for step in range(1, 4):
+                p.grad = dev(dg.uniform(f"g7/{name}/g{step}", (257,), -1, 1), T)
+                opt.step()
+                if step == 1:
+                    assert np.abs(host(p) - g[name + "_p1"]).max() < tol
+            assert np.abs(host(p) - g[name + "_p3"]).max() < tol, name
