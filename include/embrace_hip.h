@@ -107,7 +107,8 @@ int emb_linear_bwd(const void* dY, const uint8_t* mask, const void* X, const voi
  *                (filled by an all-reduce under data parallelism), else computed in-kernel and written
  *   loss  [1] fp32 out: sum_i w[y_i] nll_i / sum_i w[y_i]  (local numerator / global denominator under DP)
  *   dlogits [B,2] T out (nullable): d loss / d logits
- *   confusion [4] int64 out (nullable): TP, predicted-positive, positive, n  (accumulated: +=) */
+ *   confusion [4] int64 out (nullable): TP, predicted-positive, positive, n of THIS call's rows (written;
+ *                the caller keeps one slot per step and evaluates AP / P / R / F1 once per epoch) */
 int emb_weighted_ce(const void* logits, const int64_t* target, int64_t* class_counts, int global_counts,
                     float* loss, void* dlogits, int64_t* confusion, int B, int dtype, emb_stream_t stream);
 

@@ -75,10 +75,10 @@ __global__ __launch_bounds__(kCeThreads) void weighted_ce_kernel(const T* __rest
   if (tid == 0) {
     loss[0] = (float)(num / den);
     if (confusion != nullptr) {
-      confusion[0] += tp;
-      confusion[1] += pp;
-      confusion[2] += pos_local;
-      confusion[3] += B;
+      confusion[0] = tp;
+      confusion[1] = pp;
+      confusion[2] = pos_local;
+      confusion[3] = B;
     }
   }
 }

@@ -150,7 +150,7 @@ def linear(x, w, b, relu=False, dropout_p=0.0, layer_id=0, rng=None, compute_dty
 
 class _WeightedCEFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, logits, target, class_counts, global_counts, confusion):
+    def forward(ctx, logits, target, class_counts, global_counts, confusion, loss_out):
         _lib.require_cuda(logits, target)
         T = logits.dtype
         z = logits if logits.is_contiguous() else logits.contiguous()
@@ -158,7 +158,7 @@ class _WeightedCEFn(torch.autograd.Function):
         B = z.shape[0]
         if z.shape[1] != 2:
             raise NotImplementedError("weighted CE kernel implements the reference's 2-class task")
-        loss = torch.empty(1, dtype=torch.float32, device=z.device)
+        loss = loss_out if loss_out is not None else torch.empty(1, dtype=torch.float32, device=z.device)
         dz = torch.empty_like(z)
         check(_lib.lib().emb_weighted_ce(ptr(z), ptr(tgt), ptr(class_counts), int(bool(global_counts)), ptr(loss), ptr(dz),
                                          ptr(confusion), B, DTYPE_CODE[T], stream()), "emb_weighted_ce")
@@ -168,17 +168,18 @@ class _WeightedCEFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, g):
         (dz,) = ctx.saved_tensors
-        return dz * g.to(dz.dtype), None, None, None, None
+        return dz * g.to(dz.dtype), None, None, None, None, None
 
 
-def weighted_ce(logits, target, class_counts=None, global_counts=False, confusion=None):
+def weighted_ce(logits, target, class_counts=None, global_counts=False, confusion=None, loss_out=None):
     """Per-batch class-weighted 2-class cross-entropy of the reference's train/eval step
     (utils/utils.py:121-140, training_models_multimodal.py:140-141,151-154), loss in fp32.
     class_counts: int64[2] device tensor; written (pos, n) unless global_counts (then read).
-    confusion: optional int64[4] device accumulator (TP, predicted-positive, positive, n)."""
+    confusion: optional int64[4] device slot, written with (TP, predicted-positive, positive, n) of this batch.
+    loss_out: optional fp32[1] device slot that receives the loss (e.g. a row of metrics.StepTable)."""
     if class_counts is None:
         class_counts = torch.empty(2, dtype=torch.int64, device=logits.device)
-    return _WeightedCEFn.apply(logits, target, class_counts, global_counts, confusion)
+    return _WeightedCEFn.apply(logits, target, class_counts, global_counts, confusion, loss_out)
 
 
 def count_labels(target, out=None):

@@ -1,0 +1,407 @@
+"""Train / evaluate / tune harness with the reference's call surface
+(BIOINF_tesi/models/utils/training_models_multimodal.py): ``fit_multimodal`` (:40-226),
+``Param_Search_Multimodal`` (:232-462), ``Kfold_CV_Multimodal`` (:475-798).
+
+What changes relative to the reference is only *where* the step runs:
+  * forward / loss / backward / optimizer are HIP kernels enqueued on one stream;
+  * nothing is read back per step -- the reference's ``loss.item()`` (:160) and sklearn AUPRC (:162) are
+    replaced by a device-resident table of (loss, TP, PP, P, n) per step, fetched once per epoch and
+    turned into the same scores by closed forms (metrics.py);
+  * with torch.distributed initialised (one process per GPU, RCCL) every global batch is sharded by rows
+    across ranks (dist.py).
+Orchestration that never touches the device (Optuna study handling, the CV split, data preparation) is
+host code kept for API compatibility; its third-party dependencies are imported lazily.
+"""
+import copy
+import os
+from collections import defaultdict
+
+import numpy as np
+import torch
+
+from . import dist as D
+from . import functional as F_
+from . import metrics as M
+from . import optim as fused_optim
+
+CELL_LINES = ['A549', 'GM12878', 'H1', 'HEK293', 'HEPG2', 'K562', 'MCF7']
+TASKS = ['active_E_vs_inactive_E', 'active_P_vs_inactive_P', 'active_E_vs_active_P',
+         'inactive_E_vs_inactive_P', 'active_EP_vs_inactive_rest']
+
+# The reference always trains in fp64 (model.double(), :115/:328).  "float32" and "bfloat16" are the
+# fast settings of this engine (bf16 = bf16 activations/weight shadows, fp32 masters and accumulation).
+DEFAULT_PRECISION = "float64"
+_PRECISIONS = {"float64": torch.float64, "float32": torch.float32, "bfloat16": torch.bfloat16}
+
+
+def set_default_precision(name):
+    global DEFAULT_PRECISION
+    if name not in _PRECISIONS:
+        raise ValueError(f"precision must be one of {sorted(_PRECISIONS)}")
+    DEFAULT_PRECISION = name
+
+
+def _check_names(cell_line, task):
+    if cell_line not in CELL_LINES:
+        raise ValueError(f"Argument 'cell_line' has an incorrect value: use one among {CELL_LINES}")
+    if task not in TASKS:
+        raise ValueError(f"Argument 'task' has an incorrect value: use one among {TASKS} ")
+
+
+def prepare_model(model, device, precision=None):
+    """model.double().to(device) of the reference (:115), generalised to the engine's precisions."""
+    precision = precision or DEFAULT_PRECISION
+    dt = _PRECISIONS[precision]
+    if dt == torch.bfloat16:
+        model = model.float()
+        if hasattr(model, "set_compute_dtype"):
+            model.set_compute_dtype(torch.bfloat16)
+    else:
+        model = model.to(dt)
+        if hasattr(model, "set_compute_dtype"):
+            model.set_compute_dtype(None)
+    return model.to(device)
+
+
+def _input_dtype(model):
+    return next(model.parameters()).dtype
+
+
+def _is_embracenet(model):
+    return type(model).__name__ == 'EmbraceNetMultimodal'    # the reference switches on this string (:146)
+
+
+class StepRunner:
+    """One train or eval step of training_models_multimodal.py:132-163 / :167-192 on device tensors."""
+
+    def __init__(self, model, optimizer, device):
+        self.model, self.optimizer, self.device = model, optimizer, device
+        self.bucket = D.GradBucket(model.parameters()) if optimizer is not None else None
+        self.counts = torch.zeros(2, dtype=torch.int64, device=device)
+
+    def _shard(self, x_1, x_2, target):
+        world = D.world_size()
+        B = x_1.shape[0]
+        if world == 1:
+            return x_1, x_2, target, 0
+        row0, rows = D.shard_rows(B, D.rank(), world)
+        sl = slice(row0, row0 + rows)
+        return x_1[sl], x_2[sl], target[sl], row0
+
+    def _forward_loss(self, x_1, x_2, target, training, table):
+        model, dev = self.model, self.device
+        x_1, x_2, target, row0 = self._shard(x_1, x_2, target)
+        dt = _input_dtype(model)
+        x_1 = x_1.to(dev, dtype=dt, non_blocking=True)
+        x_2 = x_2.to(dev, dtype=dt, non_blocking=True)
+        tgt = target.to(dev, non_blocking=True).reshape(-1)
+        if hasattr(model, "rng_row0"):
+            model.rng_row0 = row0
+        global_counts = D.world_size() > 1
+        if global_counts:                                   # class weights of the GLOBAL batch
+            F_.count_labels(tgt, out=self.counts)
+            D.allreduce_counts(self.counts)
+        if training and _is_embracenet(model):
+            output = model([x_1, x_2], is_training=True)
+        else:
+            output = model([x_1, x_2])
+        loss_slot, count_slot = table.slot()
+        loss = F_.weighted_ce(output, tgt, class_counts=self.counts, global_counts=global_counts,
+                              confusion=count_slot, loss_out=loss_slot)
+        return output, loss
+
+    def train_step(self, x_1, x_2, target, table):
+        self.optimizer.zero_grad()
+        output, loss = self._forward_loss(x_1, x_2, target, True, table)
+        loss.backward()
+        self.bucket.allreduce()
+        self.optimizer.step()
+        return output, loss
+
+    def eval_step(self, x_1, x_2, target, table):
+        with torch.no_grad():
+            return self._forward_loss(x_1, x_2, target, False, table)
+
+
+def _epoch_scores(table, n_batches_for_mean):
+    """losses / counts table -> (sum of losses, mean AUPRC, mean macro P/R/F1) with the reference's
+    divisor len(loader['FFNN']) (:195-197)."""
+    losses, counts = table.fetch()
+    if D.world_size() > 1:                                   # shards -> global batches
+        t = torch.from_numpy(np.concatenate([counts.reshape(-1), (losses * 1e9).astype(np.int64)]))
+        dev = "cuda" if torch.cuda.is_available() and torch.distributed.get_backend() == "nccl" else "cpu"
+        t = t.to(dev)
+        torch.distributed.all_reduce(t)
+        t = t.cpu().numpy()
+        counts, losses = t[:counts.size].reshape(-1, 4), t[counts.size:] / 1e9
+    ap = sum(M.ap_from_counts(*map(int, c)) for c in counts)
+    prf = sum((M.prf_from_counts(*map(int, c)) for c in counts), np.zeros(3))
+    return float(losses.sum()), ap / n_batches_for_mean, prf / n_batches_for_mean
+
+
+def _pairs(loader):
+    for load1, load2 in zip(loader['FFNN'], loader['CNN']):
+        x_1, target = load1
+        x_2, _t = load2
+        assert (len(x_1) == len(x_2))
+        if not target.is_cuda:                               # the reference's alignment assert (:136); on host only
+            assert (torch.eq(target, _t).all())
+        yield x_1, x_2, target
+
+
+def fit_multimodal(model, train_loader, test_loader, device, cell_line, task, optimizer=None, num_epochs=100,
+                   patience=4, delta=0, verbose=True, checkpoint_path=None, precision=None):
+    """Train `model`, or reload it and its scores when `checkpoint_path` exists.
+    Returns (AUPRC_train_scores, AUPRC_test_scores, F1_precision_recall_test_scores), one entry per epoch."""
+    _check_names(cell_line, task)
+    if checkpoint_path is not None and os.path.exists(checkpoint_path):
+        checkpoint = torch.load(checkpoint_path, map_location=torch.device(device), weights_only=False)
+        model.load_state_dict(checkpoint['model_state_dict'])
+        return (checkpoint['AUPRC_train_scores'], checkpoint['AUPRC_test_scores'],
+                checkpoint['F1_precision_recall_test_scores'])
+    if optimizer is None:
+        raise ValueError("fit_multimodal needs an optimizer built on model.parameters()")
+
+    AUPRC_train_scores, AUPRC_test_scores, F1_precision_recall_test_scores = [], [], []
+    model = prepare_model(model, device, precision)
+    early_stopping = M.EarlyStopping(patience=patience, delta=delta, verbose=True)
+    runner = StepRunner(model, optimizer, device)
+    cap = max(len(train_loader['FFNN']), len(test_loader['FFNN'])) + 2   # BalancePos sampler yields len+1 batches
+    table = M.StepTable(cap, device)
+
+    try:
+        from tqdm.auto import tqdm
+        epochs = tqdm(range(1, num_epochs + 1), desc='Epochs')
+    except Exception:                                        # pragma: no cover
+        epochs = range(1, num_epochs + 1)
+    for epoch in epochs:
+        model.train()
+        for x_1, x_2, target in _pairs(train_loader):
+            runner.train_step(x_1, x_2, target, table)
+        train_loss, AUPRC_train, _ = _epoch_scores(table, len(train_loader['FFNN']))
+
+        model.eval()
+        for x_1, x_2, target in _pairs(test_loader):
+            runner.eval_step(x_1, x_2, target, table)
+        test_loss, AUPRC_test, F1_precision_recall_test = _epoch_scores(table, len(test_loader['FFNN']))
+
+        AUPRC_train_scores.append(AUPRC_train)
+        AUPRC_test_scores.append(AUPRC_test)
+        F1_precision_recall_test_scores.append(F1_precision_recall_test)
+        if verbose is True:
+            print('Epoch: {} \tTraining AUPRC score: {:.4f} \tTest AUPRC score: {:.4f} \tTraining Loss: {:.4f} '
+                  '\tTest Loss: {:.4f}'.format(epoch, AUPRC_train, AUPRC_test, train_loss, test_loss))
+        early_stopping(AUPRC_test)
+        if early_stopping.early_stop:
+            print('Early stopping the training')
+            break
+
+    if checkpoint_path:
+        torch.save({'model_state_dict': model.state_dict(), 'AUPRC_train_scores': AUPRC_train_scores,
+                    'AUPRC_test_scores': AUPRC_test_scores,
+                    'F1_precision_recall_test_scores': F1_precision_recall_test_scores}, checkpoint_path)
+    return AUPRC_train_scores, AUPRC_test_scores, F1_precision_recall_test_scores
+
+
+def make_optimizer(name, params, lr, weight_decay):
+    """The three optimizers of the reference's search space (:318-325) as fused HIP kernels."""
+    return getattr(fused_optim, name)(params, lr=lr, weight_decay=weight_decay)
+
+
+class Param_Search_Multimodal:
+    """Optuna hyper-parameter search (training_models_multimodal.py:232-462).  `model` is the model CLASS;
+    each trial builds it from the trial, trains with per-epoch pruning and saves it whole."""
+
+    def __init__(self, model, train_loader, test_loader, num_epochs, study_name, device, cell_line, task,
+                 sampler='TPE', n_trials=3, storage='BIOINF_optuna_tuning.db', precision=None):
+        _check_names(cell_line, task)
+        self.model_ = copy.deepcopy(model)
+        self.train_loader, self.test_loader = train_loader, test_loader
+        self.num_epochs, self.study_name, self.device = num_epochs, study_name, device
+        self.cell_line, self.task, self.n_trials, self.storage = cell_line, task, n_trials, storage
+        self.precision = precision
+        self.model_name = model.__name__
+        self.sampler_name = sampler
+
+    def _sampler(self):
+        import optuna
+        if self.sampler_name == 'BO':
+            from optuna.integration import BoTorchSampler
+            return BoTorchSampler()
+        if self.sampler_name == 'random':
+            return optuna.samplers.RandomSampler()
+        return optuna.samplers.TPESampler()
+
+    def objective(self, trial):
+        in_features_FFNN = M.get_input_size(self.train_loader['FFNN'])
+        self.model = self.model_(trial, cell_line=self.cell_line, task=self.task, device=self.device,
+                                 in_features_FFNN=in_features_FFNN)
+        optimizer_name = trial.suggest_categorical("optimizer", ["Nadam", "Adam", "RMSprop"])
+        suggest_log = getattr(trial, "suggest_loguniform", None) or \
+            (lambda n, lo, hi: trial.suggest_float(n, lo, hi, log=True))
+        lr = suggest_log("lr", 1e-5, 1e-1)
+        weight_decay = suggest_log("weight_decay", 1e-4, 1e-1)
+        self.model = prepare_model(self.model, self.device, self.precision)
+        optimizer = make_optimizer(optimizer_name, self.model.parameters(), lr, weight_decay)
+        early_stopping = M.EarlyStopping(patience=4, verbose=True)
+        runner = StepRunner(self.model, optimizer, self.device)
+        table = M.StepTable(max(len(self.train_loader['FFNN']), len(self.test_loader['FFNN'])) + 2, self.device)
+        AUPRC_test = 0.0
+        for epoch in range(1, self.num_epochs + 1):
+            self.model.train()
+            for x_1, x_2, target in _pairs(self.train_loader):
+                runner.train_step(x_1, x_2, target, table)
+            table.fetch()
+            self.model.eval()
+            for x_1, x_2, target in _pairs(self.test_loader):
+                runner.eval_step(x_1, x_2, target, table)
+            _, AUPRC_test, _ = _epoch_scores(table, len(self.test_loader['FFNN']))
+            trial.report(AUPRC_test, epoch)
+            if trial.should_prune():
+                import optuna
+                raise optuna.exceptions.TrialPruned()
+            early_stopping(AUPRC_test)
+            if early_stopping.early_stop:
+                print('Early stopping the training')
+                break
+        torch.save(self.model, f'{self.study_name}{trial.number}.pt')
+        return AUPRC_test
+
+    def run_trial(self):
+        import optuna
+        study = optuna.create_study(study_name=self.study_name, direction="maximize",
+                                    pruner=optuna.pruners.PatientPruner(optuna.pruners.MedianPruner(), patience=2),
+                                    storage=f'sqlite:///{self.storage}', load_if_exists=True, sampler=self._sampler())
+        done = lambda st: [t for t in study.trials if t.state == st]
+        complete = done(optuna.trial.TrialState.COMPLETE)
+        if len(complete) < self.n_trials:
+            self.n_trials -= len(complete)
+            study.optimize(self.objective, n_trials=self.n_trials)
+        self.best_model = torch.load(f'{self.study_name}{study.best_trial.number}.pt', torch.device(self.device),
+                                     weights_only=False)
+        print("Study statistics: ")
+        print("  Number of finished trials: ", len(study.trials))
+        print("  Number of pruned trials: ", len(done(optuna.trial.TrialState.PRUNED)))
+        print("  Number of complete trials: ", len(done(optuna.trial.TrialState.COMPLETE)))
+        trial = study.best_trial
+        self.best_params = trial.params
+        print("Best trial:\n  Value: ", trial.value, "\n  Params: ")
+        for key, value in trial.params.items():
+            print("    {}: {}".format(key, value))
+
+
+def dd():
+    return defaultdict(list)
+
+
+def path_augmentation(augmentation):
+    return '_augmentation' if augmentation else ''
+
+
+class Kfold_CV_Multimodal:
+    """k-fold cross-validation driver (training_models_multimodal.py:475-798): per fold, tune on a
+    train/validation split, re-initialise the best model and train/test it.  Data handling is the
+    reference's own ``BIOINF_tesi.data_pipe`` (out of scope of this engine, imported when called)."""
+
+    def __init__(self):
+        self.scores_dict = defaultdict(dd)
+        self.scores_dict['final_test_AUPRC_scores'] = []
+        self.scores_dict['final_train_AUPRC_scores'] = []
+        self.model_, self.optimizer = [], []
+        self.best_params = defaultdict(dict)
+
+    def build_dataloader_forCV(self, X, y, sequence, batch_size=100, training=True, augmentation=False):
+        import pandas as pd
+        from torch.utils.data import DataLoader
+        from BIOINF_tesi.data_pipe.dataprepare import BalancePos_BatchSampler, Dataset_Wrap
+        from BIOINF_tesi.data_pipe.utils import data_augmentation, data_rebalancing, get_imbalance
+        if isinstance(X, list):
+            for x_ in X:
+                x_.reset_index(drop=True, inplace=True)
+            for y_ in y:
+                y_.reset_index(drop=True, inplace=True)
+            X, y = pd.concat(list(X)), pd.concat(list(y))
+        else:
+            X.reset_index(drop=True, inplace=True), y.reset_index(drop=True, inplace=True)
+        if training:
+            if augmentation:
+                X, y = data_augmentation(X, y, sequence=sequence, rebalance_threshold=self.rebalance_threshold)
+            elif get_imbalance(y) < self.rebalance_threshold:
+                X, y = data_rebalancing(X, y, sequence=sequence, rebalance_threshold=self.rebalance_threshold)
+        wrap = Dataset_Wrap(X, y, sequence=sequence)
+        if training:
+            return DataLoader(dataset=wrap, batch_sampler=BalancePos_BatchSampler(wrap, batch_size=batch_size))
+        return DataLoader(dataset=wrap, batch_size=batch_size * 2, shuffle=True,
+                          generator=torch.Generator().manual_seed(self.random_state + 30))
+
+    def hyper_tuning(self, train_loader, test_loader, num_epochs, cell_line, task, study_name, device, sampler):
+        param_search = Param_Search_Multimodal(model=self.model_, train_loader=train_loader, test_loader=test_loader,
+                                               num_epochs=num_epochs, cell_line=cell_line, task=task, device=device,
+                                               sampler=sampler, n_trials=3, study_name=study_name,
+                                               precision=self.precision)
+        param_search.run_trial()
+        best_params = param_search.best_params
+        self.model_ = param_search.best_model
+        self.best_params[self.i] = best_params
+        self.model_.apply(M.weight_reset)
+        self.optimizer = make_optimizer(best_params['optimizer'], self.model_.parameters(), best_params['lr'],
+                                        best_params['weight_decay'])
+
+    def model_testing(self, train_loader, test_loader, num_epochs, test_model_path, device, cell_line, task,
+                      checkpoint_path=None):
+        AUPRC_train, AUPRC_test, other_scores = fit_multimodal(
+            model=self.model_, train_loader=train_loader, test_loader=test_loader, device=device, cell_line=cell_line,
+            task=task, optimizer=self.optimizer, num_epochs=num_epochs, patience=4, verbose=False,
+            checkpoint_path=f'{checkpoint_path}.pt', precision=self.precision)
+        it = self.scores_dict[f'iteration_n_{self.i}']
+        it['AUPRC_train'], it['AUPRC_test'], it['F1_precision_recall'] = AUPRC_train, AUPRC_test, other_scores
+        final_test, final_train = AUPRC_test[-1], AUPRC_train[-1]
+        self.scores_dict['final_test_AUPRC_scores'].append(final_test)
+        self.scores_dict['final_train_AUPRC_scores'].append(final_train)
+        print(f'AUPRC test score: {final_test}\n\n')
+        self.avg_score.append(final_test)
+        if final_test == max(self.avg_score):
+            os.makedirs('models_', exist_ok=True)
+            torch.save({'model_state_dict': self.model_.state_dict(), 'model_params': self.best_params[self.i]},
+                       f'models_/{test_model_path}.pt')
+
+    def __call__(self, build_dataloader_pipeline, cell_line, device, task=None, model=None, augmentation=False,
+                 rebalance_threshold=0.1, random_state=789, n_folds=3, num_epochs=100, batch_size=100,
+                 study_name=None, sampler='TPE', test_model_path=None, precision=None):
+        from sklearn.model_selection import train_test_split
+        _check_names(cell_line, task)
+        self.n_folds, self.augmentation, self.rebalance_threshold = n_folds, augmentation, rebalance_threshold
+        self.random_state, self.device, self.precision = random_state, device, precision
+        self.avg_score, self.hp_score = [], []
+        data_class = build_dataloader_pipeline.data_class
+        kf, X_1, y = data_class.return_index_data_for_cv(cell_line=cell_line, sequence=False, n_folds=n_folds,
+                                                         random_state=self.random_state)
+        _, X_2, _ = data_class.return_index_data_for_cv(cell_line=cell_line, sequence=True, n_folds=n_folds,
+                                                        random_state=self.random_state)
+        for i, (train_index, test_index) in enumerate(kf.split(X_1)):
+            self.i = i + 1
+            STUDY_NAME = f'{study_name}_{str(self.i)}'
+            print(f'>>> ITERATION N. {self.i}')
+            X_train_1, X_test_1 = X_1.iloc[train_index], X_1.iloc[test_index]
+            X_train_2, X_test_2 = X_2.iloc[train_index], X_2.iloc[test_index]
+            y_train, y_test = y.iloc[train_index], y.iloc[test_index]
+            X_train_1, X_val_1, _, _ = train_test_split(X_train_1, y_train, test_size=1 / self.n_folds,
+                                                        random_state=self.random_state, shuffle=True)
+            X_train_2, X_val_2, y_train, y_val = train_test_split(X_train_2, y_train, test_size=1 / self.n_folds,
+                                                                  random_state=self.random_state, shuffle=True)
+            self.model_ = model
+            print('\n===============> HYPERPARAMETERS TUNING')
+            mk = lambda Xa, Xb, yy, tr, aug: {
+                'FFNN': self.build_dataloader_forCV(Xa, yy, sequence=False, batch_size=batch_size, training=tr, augmentation=aug),
+                'CNN': self.build_dataloader_forCV(Xb, yy, sequence=True, batch_size=batch_size, training=tr, augmentation=aug)}
+            self.hyper_tuning(mk(X_train_1, X_train_2, y_train, True, self.augmentation),
+                              mk(X_val_1, X_val_2, y_val, False, False), num_epochs, cell_line, task, STUDY_NAME,
+                              device, sampler)
+            print('\n===============> MODEL TESTING')
+            train_loader = mk([X_train_1, X_val_1], [X_train_2, X_val_2], [y_train, y_val], True, self.augmentation)
+            test_loader = mk(X_test_1, X_test_2, y_test, False, False)
+            self.model_testing(train_loader, test_loader, num_epochs, test_model_path, device, cell_line, task,
+                               checkpoint_path=f'{cell_line}_{model.__name__}{path_augmentation(self.augmentation)}_{task}_{self.i}_test_')
+        avg_CV_AUPRC = np.round(sum(self.avg_score) / n_folds, 5)
+        self.scores_dict['average_CV_AUPRC'] = avg_CV_AUPRC
+        print(f'\n{n_folds}-FOLD CROSS-VALIDATION AUPRC TEST SCORE: {avg_CV_AUPRC}')

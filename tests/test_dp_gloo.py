@@ -1,0 +1,98 @@
+"""CPU, world_size 2, gloo: the data-parallel contract of the train step.
+
+The kernels cannot run here, so each rank computes its shard with the numpy oracle (test infrastructure) and
+the package's own DP plumbing (dist.shard_rows, dist.allreduce_counts, dist.GradBucket) must reproduce the
+single-process result: global class weights, SUMMED gradients, and a selection index tensor that does not depend
+on how the batch is sharded (Philox keyed on the global row)."""
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as tdist
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _problem():
+    from oracle import datagen as dg
+    B, d0, d1, c = 48, 8, 40, 24
+    X = [dg.uniform("dp/x0", (B, d0)), dg.uniform("dp/x1", (B, d1))]
+    W = [dg.weight("dp/w0", (c, d0), d0), dg.weight("dp/w1", (c, d1), d1)]
+    b = [dg.weight("dp/b0", (c,), d0), dg.weight("dp/b1", (c,), d1)]
+    Wp, bp = dg.weight("dp/wp", (2, c), c), dg.weight("dp/bp", (2,), c)
+    y = dg.labels("dp/y", B, 0.3)
+    return B, c, X, W, b, Wp, bp, y
+
+
+def _shard_grads(rows, pos_n, seed, step):
+    """oracle forward/backward of rows [r0, r0+n) with GLOBAL (pos, n) class counts; returns loss numerator share
+    and parameter gradients."""
+    from oracle import embrace_oracle as orc
+    B, c, X, W, b, Wp, bp, y = _problem()
+    r0, n = rows
+    sl = slice(r0, r0 + n)
+    gidx = (np.arange(r0, r0 + n, dtype=np.uint64)[:, None] * np.uint64(c) + np.arange(c, dtype=np.uint64)[None, :])
+    u = orc.philox_uniform53(seed, (step << 8) | 0, gidx)
+    idx = orc.embrace_indices(orc.selection_cdf(np.repeat(np.array([[0.4, 0.6]], np.float32), n, 0)), u)
+    Xs = [x[sl] for x in X]
+    E, Z = orc.embrace_forward(Xs, W, b, idx)
+    logits, _ = orc.linear_forward(E, Wp, bp, relu=False)
+    pos, tot = pos_n
+    w = orc.class_weights(np.array([1] * pos + [0] * (tot - pos)))
+    t = y[sl].reshape(-1)
+    zmax = logits.max(1, keepdims=True)
+    lse = zmax[:, 0] + np.log(np.exp(logits - zmax).sum(1))
+    den = w[1] * pos + w[0] * (tot - pos)
+    wy = w[t]
+    loss = (wy * (lse - logits[np.arange(n), t])).sum() / den
+    oh = np.zeros_like(logits); oh[np.arange(n), t] = 1
+    dz = (np.exp(logits - lse[:, None]) - oh) * (wy / den)[:, None]
+    dE, dWp, dbp = orc.linear_backward(dz, E, Wp, logits, relu=False)
+    dX, dW, db = orc.embrace_backward(dE, Xs, W, Z, idx)
+    return loss, [dW[0], db[0], dW[1], db[1], dWp, dbp], idx
+
+
+def _worker(rank, world, port, out):
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      LOCAL_RANK=str(rank))
+    import embracenet_amd  # noqa: F401
+    from embracenet_amd import dist
+    r, _, w = dist.init(backend="gloo")
+    assert (r, w) == (rank, world) and dist.world_size() == world
+    B, c, X, W, b, Wp, bp, y = _problem()
+    rows = dist.shard_rows(B, rank, world)
+    local = y[rows[0]:rows[0] + rows[1]]
+    counts = torch.tensor([int(local.sum()), len(local)], dtype=torch.int64)
+    dist.allreduce_counts(counts)
+    loss, grads, idx = _shard_grads(rows, tuple(counts.tolist()), seed=21, step=4)
+    params = [torch.nn.Parameter(torch.zeros(g.shape, dtype=torch.float64)) for g in grads]
+    for p, g in zip(params, grads):
+        p.grad = torch.from_numpy(np.ascontiguousarray(g))
+    dist.GradBucket(params).allreduce()
+    total = torch.tensor([loss], dtype=torch.float64)
+    tdist.all_reduce(total)
+    if rank == 0:
+        np.savez(out, loss=total.numpy(), counts=counts.numpy(), **{f"g{i}": p.grad.numpy() for i, p in enumerate(params)})
+    np.save(out + f".idx{rank}.npy", idx)
+    dist.barrier()
+    tdist.destroy_process_group()
+
+
+def test_two_rank_step_equals_single_process(tmp_path):
+    out = str(tmp_path / "dp.npz")
+    port = 29500 + (os.getpid() % 2000)
+    mp.spawn(_worker, args=(2, port, out), nprocs=2, join=True)
+    got = np.load(out)
+    B, c, X, W, b, Wp, bp, y = _problem()
+    pos = int(y.sum())
+    assert got["counts"].tolist() == [pos, B]
+    loss, grads, idx = _shard_grads((0, B), (pos, B), seed=21, step=4)
+    assert abs(float(got["loss"][0]) - loss) < 1e-12
+    for i, g in enumerate(grads):
+        assert np.abs(got[f"g{i}"] - g).max() < 1e-12, i
+    halves = np.concatenate([np.load(out + f".idx{r}.npy") for r in range(2)])
+    assert np.array_equal(halves, idx), "selection indices depend on the sharding"

@@ -1,0 +1,173 @@
+"""GPU parity of the whole drop-in model / train step against the golden fixtures generated from the imported
+reference (G2 eval logits, G3 train step with gradients, G9 fit trajectory) -- `pytest -m gpu`.
+
+Host-RNG ("parity") mode: the module draws the reference's random numbers from torch's CPU generator in the
+reference's order and injects them, so the index tensor must be bit-exact and everything else agrees to
+rounding.  Tolerances: fp64 models 1e-9 (logits) / 1e-8 relative (gradients, trained parameters);
+fp32 models 1e-5 on logits (the north-star bar).
+"""
+import numpy as np
+import pytest
+import torch
+
+from helpers import Golden, model_batch, model_fill, unpack_idx
+from oracle import datagen as dg
+from oracle.configs import CONFIGS, FixedTrial
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+
+
+def build(ea, cfg_name, tag, dtype=torch.float64):
+    hp, F_in = CONFIGS[cfg_name]
+    trial = FixedTrial(hp)
+    model = ea.EmbraceNetMultimodal(trial, cell_line="A549", task="active_E_vs_inactive_E", device=DEV,
+                                    in_features_FFNN=F_in)
+    fill = model_fill(tag)
+    model = model.double()
+    with torch.no_grad():
+        for key, t in model.state_dict().items():
+            if "running_" in key or "num_batches" in key:
+                continue
+            t.copy_(torch.from_numpy(fill(key, tuple(t.shape))))
+    model = model.to(dtype).to(DEV).set_rng("host")
+    return model, trial, hp, F_in
+
+
+def batch(tag, B, F_in, dtype, rate=0.1):
+    x1, x2, y = model_batch(tag, B, F_in, rate)
+    return torch.from_numpy(x1).to(DEV, dtype), torch.from_numpy(x2).to(DEV, dtype), torch.from_numpy(y).to(DEV)
+
+
+@pytest.mark.parametrize("i", range(4))
+@pytest.mark.parametrize("dtype", [torch.float64, torch.float32])
+def test_g2_eval_logits(ea, i, dtype):
+    g = Golden("G2_model_eval_logits")
+    case = g.meta["cases"][i]
+    model, trial, hp, F_in = build(ea, case["cfg"], case["tag"], dtype)
+    assert trial.calls == case["trial_calls"], "Optuna trial call order differs from the reference"
+    assert sum(p.numel() for p in model.parameters()) == case["n_params"]
+    x1, x2, _ = batch(f"{case['tag']}/B{case['B']}", case["B"], F_in, dtype)
+    model.eval()
+    torch.manual_seed(case["seed"])
+    out = model([x1, x2])
+    idx = model.embracenet.modality_indices().cpu().numpy()
+    assert np.array_equal(idx, unpack_idx(g[case["key"] + "_idx"], case["B"], hp["EMBRACENET_embracement_size"]))
+    err = np.abs(out.detach().double().cpu().numpy() - g[case["key"] + "_logits"]).max()
+    assert err < (1e-9 if dtype == torch.float64 else 1e-5), err
+
+
+@pytest.mark.parametrize("i", range(4))
+def test_g3_train_step_gradients(ea, i):
+    g = Golden("G3_model_train_step")
+    case = g.meta["cases"][i]
+    key = case["key"]
+    model, trial, hp, F_in = build(ea, case["cfg"], case["tag"])
+    x1, x2, y = batch(f"{case['tag']}/B{case['B']}", case["B"], F_in, torch.float64)
+    model.train()
+    cap = {}
+
+    def hook(mod, args, kwargs):
+        cap["in"] = list(args[0])
+        for t in cap["in"]:
+            t.retain_grad()
+    h = model.embracenet.register_forward_pre_hook(hook, with_kwargs=True)
+    torch.manual_seed(case["seed"])
+    out = model([x1, x2], is_training=True)
+    h.remove()
+    c = hp["EMBRACENET_embracement_size"]
+    idx = model.embracenet.modality_indices().cpu().numpy()
+    assert np.array_equal(idx, unpack_idx(g[key + "_idx"], case["B"], c))
+    if case["dropped"]:     # every row used exactly the modality the reference drew for it
+        t = g[key + "_t"].astype(np.int64)
+        assert np.array_equal(idx, np.repeat(t[:, None], c, 1))
+    assert np.abs(out.detach().cpu().numpy() - g[key + "_logits"]).max() < 1e-9
+    loss = ea.functional.weighted_ce(out, y)
+    assert abs(loss.item() - case["loss"]) < 2e-6     # the reference's loss is fp32
+    loss.backward()
+    params = dict(model.named_parameters())
+    for name, chk in case["grads"].items():
+        got = dg.checksum(params[name].grad.cpu().numpy())
+        scale = max(chk["abs"], 1e-6)   # floor: conv biases in front of BatchNorm have a zero gradient (noise)
+        # the fp32 loss kernel rounds d(loss)/d(logits) to fp32, as the reference's fp32 criterion does
+        assert abs(got["sum"] - chk["sum"]) < 2e-6 * scale and abs(got["dot"] - chk["dot"]) < 2e-6 * scale, name
+        assert abs(got["abs"] - chk["abs"]) < 2e-6 * scale, name
+    for nm, arr in (("embracenet.docking_0.weight", "_g_dock0_w"), ("embracenet.docking_0.bias", "_g_dock0_b"),
+                    ("embracenet.docking_1.bias", "_g_dock1_b")):
+        ref = g[key + arr]
+        assert np.abs(params[nm].grad.cpu().numpy() - ref).max() < 2e-6 * max(1e-6, np.abs(ref).max()), nm
+    for m, suffix in ((0, "_dX0"), (1, "_dX1")):
+        ref = g[key + suffix].astype(np.float64)
+        assert np.abs(cap["in"][m].grad.cpu().numpy() - ref).max() < 5e-6 * max(1e-9, np.abs(ref).max())
+    sd = model.state_dict()
+    for k in case["bn_keys"]:
+        assert np.abs(sd[k].cpu().numpy() - g[key + "_bn_" + k.replace(".", "_")]).max() < 1e-10, k
+
+
+@pytest.mark.parametrize("i", range(2))
+def test_g9_fit_trajectory_matches_reference(ea, i, tmp_path):
+    from embracenet_amd import optim, training
+    g = Golden("G9_fit_trajectory")
+    case = g.meta["cases"][i]
+    model, trial, hp, F_in = build(ea, "small", case["tag"])
+    B, n_train, n_test = case["B"], case["n_train"], case["n_test"]
+    def mk(prefix, n, bs):
+        bt = [model_batch(f"{case['tag']}/{prefix}{k}", bs, F_in, 0.3) for k in range(n)]
+        t = lambda a: torch.from_numpy(a)
+        return {"FFNN": [(t(a), t(y)) for a, b, y in bt], "CNN": [(t(b), t(y)) for a, b, y in bt]}
+    cls = optim.Adam if case["opt"] == "adam" else optim.RMSprop
+    opt = cls(model.parameters(), lr=case["lr"], weight_decay=case["weight_decay"])
+    torch.manual_seed(case["seed"])
+    res = training.fit_multimodal(model, mk("train", n_train, B), mk("test", n_test, 2 * B), DEV, "A549",
+                                  "active_E_vs_inactive_E", optimizer=opt, num_epochs=case["epochs"], patience=4,
+                                  verbose=False, checkpoint_path=str(tmp_path / "ck.pt"), precision="float64")
+    assert np.allclose(res[0], case["AUPRC_train"], atol=1e-12), (res[0], case["AUPRC_train"])
+    assert np.allclose(res[1], case["AUPRC_test"], atol=1e-12)
+    assert np.allclose(np.array(res[2]), np.array(case["PRF_test"]), atol=1e-12)
+    sd = model.state_dict()
+    for name, chk in case["final"].items():
+        got = dg.checksum(sd[name].cpu().numpy())
+        assert abs(got["sum"] - chk["sum"]) < 1e-6 * max(chk["abs"], 1e-12), name
+    w = sd["embracenet.docking_0.weight"].cpu().numpy()
+    assert np.abs(w - g[case["opt"] + "_dock0_w"]).max() < 1e-6
+    # resumability: a second call with the same checkpoint path reloads scores instead of training (:95-100)
+    res2 = training.fit_multimodal(model, mk("train", 1, B), mk("test", 1, B), DEV, "A549", "active_E_vs_inactive_E",
+                                   optimizer=opt, num_epochs=1, checkpoint_path=str(tmp_path / "ck.pt"))
+    assert res2[0] == res[0]
+
+
+def test_model_is_picklable_and_resettable(ea, tmp_path):
+    from embracenet_amd import metrics
+    model, trial, hp, F_in = build(ea, "small", "pk")
+    x1, x2, _ = batch("pk/B16", 16, F_in, torch.float64)
+    model.eval()
+    model([x1, x2])
+    torch.save(model, tmp_path / "m.pt")                       # whole-object save, as the harness does (:413)
+    m2 = torch.load(tmp_path / "m.pt", weights_only=False)
+    m2.set_rng("host")
+    torch.manual_seed(3); a = model([x1, x2])
+    torch.manual_seed(3); b = m2([x1, x2])
+    assert torch.equal(a, b)
+    before = model.embracenet.docking_1.weight.clone()
+    model.apply(metrics.weight_reset)
+    assert not torch.equal(before, model.embracenet.docking_1.weight)
+
+
+def test_philox_training_step_bf16_runs_and_learns(ea):
+    """perf-mode smoke: bf16 compute, device-side RNG, fused Adam; the loss must go down on a fixed batch."""
+    from embracenet_amd import optim, training
+    model, trial, hp, F_in = build(ea, "small", "bf", torch.float32)
+    model = training.prepare_model(model, DEV, "bfloat16").set_rng("philox", seed=7)
+    x1, x2, y = batch("bf/B256", 256, F_in, torch.float32, rate=0.3)
+    y = (x1[:, 0] > 0.5).long().view(-1, 1)                    # learnable labels
+    opt = optim.Adam(model.parameters(), lr=2e-3)
+    model.train()
+    losses = []
+    for _ in range(30):
+        opt.zero_grad()
+        out = model([x1, x2], is_training=True)
+        loss = ea.functional.weighted_ce(out, y)
+        loss.backward()
+        opt.step()
+        losses.append(loss.item())
+    assert np.isfinite(losses).all() and np.mean(losses[-5:]) < np.mean(losses[:5]) - 0.02, losses

@@ -1,0 +1,106 @@
+"""CPU: the C-ABI library loads and exports every symbol the header declares; host-side logic of the package
+(no compute calls -- there is no GPU here and no CPU fallback to call)."""
+import copy
+import ctypes
+import os
+import pickle
+import re
+
+import numpy as np
+import pytest
+import torch
+
+from helpers import Golden
+from oracle.configs import CFG1, CFG1_F, CONFIGS, FixedTrial
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_library_exports_every_declared_symbol(ea):
+    header = open(os.path.join(ROOT, "include", "embrace_hip.h")).read()
+    declared = set(re.findall(r"^(?:int|const char\*)\s+(emb_\w+)\s*\(", header, flags=re.M))
+    assert len(declared) >= 14
+    assert declared == set(ea._lib.SIGNATURES), "binding table and header disagree"
+    if not os.path.exists(ea._lib.LIB_PATH):
+        ea._lib.build()
+    lib = ctypes.CDLL(ea._lib.LIB_PATH)
+    for name in declared:
+        assert hasattr(lib, name), name
+    assert ea._lib.lib().emb_abi_version() == 1
+
+
+def test_abi_rejects_bad_arguments_without_touching_a_gpu(ea):
+    L = ea._lib.lib()
+    assert L.emb_embrace_fwd(None, None, None, None, None, None, None, None, 0, 0, None, 0, None, None, 1, 1, 1, 1, 0, None) == -1
+    assert b"null pointer" in L.emb_last_error()
+    assert L.emb_cast(None, 0, None, 0, 4, None) == -1
+    assert L.emb_select_prep(ctypes.c_void_p(16), 3, None, 0, 0, 0, None, 0, ctypes.c_void_p(16), ctypes.c_void_p(16), 8, None) == -1
+    assert b"p_rows" in L.emb_last_error()
+
+
+def test_cpu_tensors_fail_loudly(ea):
+    net = ea.EmbraceNet("cpu", [4, 8], 16)
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        net([torch.zeros(2, 4), torch.zeros(2, 8)])
+
+
+def test_model_construction_mirrors_reference(ea):
+    g = Golden("G2_model_eval_logits")
+    for case in g.meta["cases"]:
+        hp, F_in = CONFIGS[case["cfg"]]
+        trial = FixedTrial(hp)
+        m = ea.EmbraceNetMultimodal(trial, cell_line="A549", task="active_E_vs_inactive_E", device="cpu",
+                                    in_features_FFNN=F_in)
+        assert trial.calls == case["trial_calls"]
+        assert sum(p.numel() for p in m.parameters()) == case["n_params"]
+        assert type(m).__name__ == "EmbraceNetMultimodal"
+    m = ea.EmbraceNetMultimodal(FixedTrial(CFG1), cell_line="A549", task="t", device="cpu", in_features_FFNN=CFG1_F)
+    keys = list(m.state_dict().keys())
+    for k in ("FFNN.model.0.weight", "FFNN.model.6.bias", "CNN.CNN_model.0.weight", "CNN.CNN_model.1.running_mean",
+              "CNN.CNN_model.6.weight", "embracenet.docking_0.weight", "embracenet.docking_1.bias", "post.0.weight"):
+        assert k in keys, k
+    assert not any("selection" in k for k in keys)                    # plain attribute, as in the reference (:157)
+    assert tuple(m.embracenet.docking_1.weight.shape) == (512, 1856) and m.CNN_pre_output_size == 1856
+    assert m.FFNN_pre_output_size == 16 and abs(float(m.selection_probabilities.sum()) - 1.0) < 1e-7
+    m2 = pickle.loads(pickle.dumps(m)); m3 = copy.deepcopy(m)          # harness: deepcopy (:277), torch.save (:413)
+    assert list(m2.state_dict().keys()) == keys == list(m3.state_dict().keys())
+    m.double(); m.train(); m.eval()
+    assert m.embracenet.docking_0.weight.dtype == torch.float64
+
+
+def test_early_stopping_and_weights(ea):
+    es = ea.EarlyStopping(patience=2, trace_func=lambda s: None)
+    for s in (0.5, 0.6, 0.55, 0.58):
+        es(s)
+    assert es.early_stop and es.best_score == 0.6
+    g = Golden("G5_weighted_ce")
+    for case in g.meta["cases"]:
+        y = torch.tensor([1] * case["pos"] + [0] * (case["B"] - case["pos"])).view(-1, 1)
+        w_pos, w_neg = ea.get_loss_weights_from_labels(y)
+        assert abs(w_pos - case["w_pos"]) < 1e-15 and abs(w_neg - case["w_neg"]) < 1e-15
+
+
+def test_shard_rows_partition():
+    from embracenet_amd import dist
+    for B in (1, 7, 64, 100, 8192):
+        for world in (1, 2, 3, 8):
+            spans = [dist.shard_rows(B, r, world) for r in range(world)]
+            assert spans[0][0] == 0 and sum(n for _, n in spans) == B
+            for (a, n), (b, _) in zip(spans, spans[1:]):
+                assert a + n == b
+
+
+def test_fit_validates_names(ea):
+    with pytest.raises(ValueError):
+        ea.fit_multimodal(None, {}, {}, "cpu", "NOPE", "active_E_vs_inactive_E")
+    with pytest.raises(ValueError):
+        ea.fit_multimodal(None, {}, {}, "cpu", "A549", "nope")
+
+
+def test_step_table_roundtrip(ea):
+    t = ea.metrics.StepTable(4, "cpu")
+    for k in range(3):
+        ls, cs = t.slot()
+        ls.fill_(0.5 * k); cs.copy_(torch.tensor([k, k + 1, k + 2, 10]))
+    losses, counts = t.fetch()
+    assert losses.tolist() == [0.0, 0.5, 1.0] and counts[2].tolist() == [2, 3, 4, 10] and t.n == 0
