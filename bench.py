@@ -1,0 +1,308 @@
+#!/usr/bin/env python3
+"""Headline benchmark: EmbraceNetMultimodal training step throughput on MI355X.
+
+    python bench.py --gpus N --steps K --warmup W
+    (N > 1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...)
+
+A "step" is one full pass of the hot path over one synthetic batch: zero_grad, forward
+(pre-nets -> fused docking/ReLU/selection -> post stack), class-weighted cross-entropy, backward, gradient
+all-reduce (N > 1), optimizer step -- the semantics of the reference's train step
+(BIOINF_tesi/models/utils/training_models_multimodal.py:132-163) without its per-step host syncs.
+Workload = BASELINE.json configs[1]: A549 two-modality EmbraceNet (trial-0 pre-nets of the Optuna DB: d0=16,
+d1=1856), docking dim c=256, per-GPU batch 1024, bf16 storage with fp32 accumulate.  Weak scaling: every GPU
+keeps 1024 rows, the global batch is 1024*N.  Inputs are resident in HBM before the timed region.
+
+One JSON line on stdout (rank 0); see DESIGN.md "Measurement" for every field.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+import torch  # noqa: E402
+
+WORKLOADS = {
+    # BASELINE.json configs[1]
+    "cfg2": dict(name="A549 2-modality EmbraceNet, c=256, B=1024/GPU, bf16", F=48, B=1024, dtype="bfloat16", pos=0.1,
+                 hp=dict(FFNN_n_layers=3, FFNN_n_units_l0=32, FFNN_dropout_l0=0.0, FFNN_n_units_l1=16, FFNN_dropout_l1=0.0,
+                         FFNN_n_units_l2=16, FFNN_dropout_l2=0.0, CNN_n_layers=2, CNN_out_channels_l0=64,
+                         CNN_kernel_size_l0=15, CNN_dropout_l0=0, CNN_out_channels_l1=32, CNN_kernel_size_l1=15,
+                         CNN_dropout_l1=0, EMBRACENET_embracement_size=256, n_post_layers=0,
+                         selection_probabilities_FFNN=0.5784523087676721)),
+}
+WORKLOADS["cfg1"] = dict(WORKLOADS["cfg2"], name="A549 2-modality EmbraceNet, c=512, B=64, fp64 (reference plumbing case)",
+                         B=64, dtype="float64", hp=dict(WORKLOADS["cfg2"]["hp"], EMBRACENET_embracement_size=512))
+WORKLOADS["cfg4"] = dict(name="K562 E-vs-P, c=1024, d1=1024, n_post=2, fp32, B=1024/GPU (MFMA-bound docking)", F=429, B=1024,
+                         dtype="float32", pos=0.306,
+                         hp=dict(FFNN_n_layers=1, FFNN_n_units_l0=64, FFNN_dropout_l0=0.0, CNN_n_layers=4,
+                                 CNN_out_channels_l0=32, CNN_kernel_size_l0=5, CNN_dropout_l0=0, CNN_out_channels_l1=32,
+                                 CNN_kernel_size_l1=5, CNN_dropout_l1=0, CNN_out_channels_l2=128, CNN_kernel_size_l2=11,
+                                 CNN_dropout_l2=0, CNN_out_channels_l3=128, CNN_kernel_size_l3=15, CNN_dropout_l3=0,
+                                 EMBRACENET_embracement_size=1024, n_post_layers=2, EMBRACENET_n_units_l0=256,
+                                 EMBRACENET_dropout_l0=0.0, EMBRACENET_n_units_l1=128, EMBRACENET_dropout_l1=0.0,
+                                 selection_probabilities_FFNN=0.5))
+
+HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s (spec); ~6.3 TB/s achievable
+MFMA_PEAK_TFLOPS = {"bfloat16": 2500.0, "float32": 157.3, "float64": 78.6}
+
+
+class DictTrial:
+    def __init__(self, p):
+        self.p = p
+
+    def suggest_int(self, n, lo, hi):
+        return self.p[n]
+
+    def suggest_categorical(self, n, ch):
+        return self.p[n]
+
+    def suggest_float(self, n, lo, hi):
+        return self.p[n]
+
+
+def synth_batch(B, F, pos, device, seed):
+    g = torch.Generator(device=device).manual_seed(seed)
+    x1 = torch.rand(B, F, device=device, generator=g)
+    base = torch.randint(0, 4, (B, 256), device=device, generator=g)
+    x2 = torch.nn.functional.one_hot(base, 4).permute(0, 2, 1).contiguous().float()
+    y = (torch.rand(B, device=device, generator=g) < pos).long()
+    return x1, x2, y
+
+
+def event_time_us(fn, iters, warm=5):
+    for _ in range(warm):
+        fn()
+    torch.cuda.synchronize()
+    t0, t1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    t0.record()
+    for _ in range(iters):
+        fn()
+    t1.record()
+    torch.cuda.synchronize()
+    return t0.elapsed_time(t1) * 1e3 / iters
+
+
+def kernel_roofline(ea, wl, device):
+    """Isolated timing of the two hand-written GEMM-class kernels of the step on this workload's shapes, with HIP
+    events on the launch stream; algorithmic bytes/flops per launch as defined in DESIGN.md."""
+    F = ea.functional
+    hp, B = wl["hp"], wl["B"]
+    T = {"bfloat16": torch.bfloat16, "float32": torch.float32, "float64": torch.float64}[wl["dtype"]]
+    P = torch.float64 if T == torch.float64 else torch.float32
+    s, sp = torch.empty(0, dtype=T).element_size(), torch.empty(0, dtype=P).element_size()
+    probe = ea.EmbraceNetMultimodal(DictTrial(hp), "A549", "active_E_vs_inactive_E", "cpu", wl["F"])
+    d0, d1, c = probe.FFNN_pre_output_size, probe.CNN_pre_output_size, hp["EMBRACENET_embracement_size"]
+    g = torch.Generator(device=device).manual_seed(1)
+    r = lambda *sh: torch.rand(*sh, device=device, generator=g)
+    x0, x1 = r(B, d0).to(T), r(B, d1).to(T)
+    w0, w1 = ((r(c, d0) - 0.5) / d0 ** 0.5).to(P), ((r(c, d1) - 0.5) / d1 ** 0.5).to(P)
+    b0, b1 = torch.zeros(c, device=device, dtype=P), torch.zeros(c, device=device, dtype=P)
+    cdf0, _ = F.select_prep(torch.tensor([[0.578, 0.422]], device=device), None, B)
+    rng = F.RngState(seed=3, step_val=1)
+    w0c, w1c = w0.to(T), w1.to(T)
+    E = torch.empty(B, c, dtype=T, device=device)
+    code = torch.empty(B, c, dtype=torch.uint8, device=device)
+    dE = (r(B, c) - 0.5).to(T)
+    dX0, dX1 = torch.empty_like(x0), torch.empty_like(x1)
+    dW0, dW1 = torch.empty(c, d0, device=device, dtype=P), torch.empty(c, d1, device=device, dtype=P)
+    db0, db1 = torch.empty(c, device=device, dtype=P), torch.empty(c, device=device, dtype=P)
+    L, ptr, st, code_of = ea._lib.lib(), ea._lib.ptr, ea._lib.stream, ea._lib.DTYPE_CODE[T]
+
+    def fwd():
+        ea._lib.check(L.emb_embrace_fwd(ptr(x0), ptr(x1), ptr(w0c), ptr(b0), ptr(w1c), ptr(b1), ptr(cdf0), None, rng.seed,
+                                        rng.step_val, None, 0, ptr(E), ptr(code), B, d0, d1, c, code_of, st()), "fwd")
+
+    def bwd():
+        ea._lib.check(L.emb_embrace_bwd(ptr(dE), ptr(code), ptr(x0), ptr(x1), ptr(w0c), ptr(w1c), ptr(dX0), ptr(dX1),
+                                        ptr(dW0), ptr(db0), ptr(dW1), ptr(db1), B, d0, d1, c, code_of, st()), "bwd")
+    fwd()
+    t_f, t_b = event_time_us(fwd, 200), event_time_us(bwd, 200)
+    K = d0 + d1
+    bytes_f = s * B * K + s * c * K + 2 * sp * c + 4 * B + s * B * c + B * c
+    bytes_b = s * B * c + B * c + s * B * K + s * c * K + s * B * K + sp * c * K + 2 * sp * c
+    flops_f, flops_b = 2.0 * B * c * K, 4.0 * B * c * K
+    out = {}
+    for name, t, by, fl in (("embrace_fwd_kernel", t_f, bytes_f, flops_f), ("embrace_bwd_kernel", t_b, bytes_b, flops_b)):
+        ai = fl / by
+        ridge = MFMA_PEAK_TFLOPS[wl["dtype"]] * 1e12 / (HBM_PEAK_GBS * 1e9)
+        if ai < ridge:
+            out[name] = dict(bound="hbm", achieved=by / t / 1e3, peak=HBM_PEAK_GBS, unit="GB/s")
+        else:
+            out[name] = dict(bound="mfma", achieved=fl / t / 1e6, peak=MFMA_PEAK_TFLOPS[wl["dtype"]], unit="TFLOP/s")
+        out[name].update(frac=out[name]["achieved"] / out[name]["peak"], us_per_launch=t, algorithmic_bytes=by,
+                         algorithmic_flops=fl, traffic=None)
+    return out, (d0, d1, c)
+
+
+def cpu_baseline(wl, seconds):
+    """The stock-PyTorch CPU restatement of the reference step (oracle/ref_step.py; fp64 like the reference, incl. its
+    per-step loss.item() and sklearn average precision), timed on this box's host cores on a bounded sample."""
+    from oracle import ref_step
+    torch.manual_seed(0)
+    hp, B, Fin = wl["hp"], wl["B"], wl["F"]
+    model = ref_step.OracleEmbraceNetMultimodal(hp, Fin)
+    with torch.no_grad():
+        for p in model.parameters():
+            if p.dim() > 1:
+                torch.nn.init.kaiming_uniform_(p, a=5 ** 0.5)
+    opt = torch.optim.Adam(model.parameters(), lr=1e-3, weight_decay=1e-3)
+    x1, x2, y = synth_batch(B, Fin, wl["pos"], "cpu", 5)
+    x1, x2, y = x1.double(), x2.double(), y.view(-1, 1)
+    model.train()
+    ref_step.train_step(model, opt, x1, x2, y)          # warm-up
+    n, t0 = 0, time.perf_counter()
+    while time.perf_counter() - t0 < seconds:
+        ref_step.train_step(model, opt, x1, x2, y)
+        n += 1
+    dt = time.perf_counter() - t0
+    return dict(value=n * B / dt, unit="samples/s", cores=torch.get_num_threads(), kind="port",
+                sample=f"{n} train steps of B={B} (same workload, fp64 as the reference trains; "
+                       f"incl. per-step loss.item() and sklearn AP), {dt:.1f} s")
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--workload", default="cfg2", choices=sorted(WORKLOADS))
+    ap.add_argument("--dtype", default=None, help="override the workload's precision")
+    ap.add_argument("--eager", action="store_true", help="no hipGraph capture")
+    ap.add_argument("--backend", default=None, help="nccl (RCCL, default) or gloo (rehearsal on one GPU)")
+    ap.add_argument("--cpu-baseline-seconds", type=float, default=15.0)
+    ap.add_argument("--no-extras", action="store_true", help="skip roofline and cpu_baseline legs")
+    args = ap.parse_args()
+
+    import embracenet_amd as ea
+    from embracenet_amd import dist as D, optim, training
+    rank, local_rank, world = D.init(backend=args.backend)
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
+    one_gpu = args.backend == "gloo"
+    device = torch.device("cuda", 0 if one_gpu else local_rank)
+    torch.cuda.set_device(device)
+    wl = dict(WORKLOADS[args.workload])
+    if args.dtype:
+        wl["dtype"] = args.dtype
+    B, Fin = wl["B"], wl["F"]
+
+    torch.manual_seed(1234)                               # identical initial weights on every rank
+    model = ea.EmbraceNetMultimodal(DictTrial(wl["hp"]), cell_line="A549", task="active_E_vs_inactive_E", device=device,
+                                    in_features_FFNN=Fin)
+    model = training.prepare_model(model, device, wl["dtype"]).set_rng("philox", seed=2024, row0=rank * B)
+    opt = optim.Adam(model.parameters(), lr=1e-3, weight_decay=1e-3)
+    x1, x2, y = synth_batch(B, Fin, wl["pos"], device, 100 + rank)
+    in_dt = next(model.parameters()).dtype
+    x1, x2 = x1.to(in_dt), x2.to(in_dt)
+    counts = torch.zeros(2, dtype=torch.int64, device=device)
+    table = ea.metrics.StepTable(1, device)
+    loss_slot, conf_slot = table.slot()
+    bucket = D.GradBucket(model.parameters())
+    F = ea.functional
+    model.train()
+
+    def fwd_bwd():
+        opt.zero_grad(set_to_none=True)
+        out = model([x1, x2], is_training=True)
+        loss = F.weighted_ce(out, y, class_counts=counts, global_counts=world > 1, confusion=conf_slot, loss_out=loss_slot)
+        loss.backward()
+
+    def pre():                                            # class weights of the GLOBAL batch (labels known up front)
+        if world > 1:
+            F.count_labels(y, out=counts)
+            D.allreduce_counts(counts)
+
+    def eager_step():
+        pre()
+        fwd_bwd()
+        bucket.allreduce()
+        opt.step()
+
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):                         # builds optimizer state, MIOpen plans, LDS attributes
+        for _ in range(3):
+            eager_step()
+    torch.cuda.current_stream().wait_stream(side)
+    torch.cuda.synchronize()
+
+    use_graph = not args.eager
+    if use_graph:
+        if world == 1:
+            g_all = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g_all):
+                fwd_bwd()
+                opt.step()
+            step = g_all.replay
+        else:                                             # collectives stay outside the captured regions
+            g_fb, g_opt = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g_fb):
+                fwd_bwd()
+            with torch.cuda.graph(g_opt, pool=g_fb.pool()):
+                opt.step()
+
+            def step():
+                pre()
+                g_fb.replay()
+                bucket.allreduce()
+                g_opt.replay()
+    else:
+        step = eager_step
+
+    for _ in range(args.warmup):
+        step()
+    torch.cuda.synchronize()
+    D.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    torch.cuda.synchronize()
+    D.barrier()
+    torch.cuda.synchronize()
+    elapsed = D.max_over_ranks(time.perf_counter() - t0, device)
+    final_loss = float(loss_slot.item())
+    if not (final_loss == final_loss):
+        raise SystemExit("loss is NaN")
+
+    result = None
+    if rank == 0:
+        value = world * B * args.steps / elapsed
+        result = {
+            "metric": "training samples/sec (EmbraceNet, A549 enhancers), whole job; per GPU = value / n_gpus",
+            "value": value, "unit": "samples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": {"bfloat16": "bf16", "float32": "f32", "float64": "f64"}[wl["dtype"]], "data": "synthetic",
+            "per_gpu": value / world,
+            "config": {"workload": wl["name"], "per_gpu_batch": B, "global_batch": B * world,
+                       "parallelism": f"dp{world} (batch-sharded, RCCL all-reduce of gradients)" if world > 1 else "single GPU",
+                       "step": "zero_grad+fwd+weighted CE+bwd" + ("+allreduce" if world > 1 else "") + "+fused Adam",
+                       "graph": bool(use_graph), "rng": "philox (device-side modality dropout and selection)",
+                       "final_loss": final_loss},
+        }
+        if world == 1 and not args.no_extras:
+            kern, dims = kernel_roofline(ea, wl, device)
+            dom = max(kern, key=lambda k: kern[k]["us_per_launch"])
+            pmc = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+            if os.path.exists(pmc):
+                for k, v in json.load(open(pmc)).get(args.workload, {}).items():
+                    if k in kern:
+                        kern[k]["traffic"] = v
+            roof = dict(kern[dom])
+            roof.update(kernel=dom, shapes=dict(B=B, d0=dims[0], d1=dims[1], c=dims[2]), kernels=kern)
+            result["roofline"] = roof
+            result["cpu_baseline"] = cpu_baseline(wl, args.cpu_baseline_seconds)
+            result["speedup_vs_cpu_baseline"] = value / result["cpu_baseline"]["value"]
+        print(json.dumps(result), flush=True)
+    D.barrier()
+    if world > 1:
+        torch.distributed.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -3,7 +3,7 @@ reference (G2 eval logits, G3 train step with gradients, G9 fit trajectory) -- `
 
 Host-RNG ("parity") mode: the module draws the reference's random numbers from torch's CPU generator in the
 reference's order and injects them, so the index tensor must be bit-exact and everything else agrees to
-rounding.  Tolerances: fp64 models 1e-9 (logits) / 1e-8 relative (gradients, trained parameters);
+rounding.  Tolerances: fp64 models 1e-9 (logits) / 1e-8 relative (gradients through the fp32 loss: 1e-5 relative; trained parameters 1e-6);
 fp32 models 1e-5 on logits (the north-star bar).
 """
 import numpy as np
@@ -90,8 +90,8 @@ def test_g3_train_step_gradients(ea, i):
         got = dg.checksum(params[name].grad.cpu().numpy())
         scale = max(chk["abs"], 1e-6)   # floor: conv biases in front of BatchNorm have a zero gradient (noise)
         # the fp32 loss kernel rounds d(loss)/d(logits) to fp32, as the reference's fp32 criterion does
-        assert abs(got["sum"] - chk["sum"]) < 2e-6 * scale and abs(got["dot"] - chk["dot"]) < 2e-6 * scale, name
-        assert abs(got["abs"] - chk["abs"]) < 2e-6 * scale, name
+        assert abs(got["sum"] - chk["sum"]) < 1e-5 * scale and abs(got["dot"] - chk["dot"]) < 1e-5 * scale, name
+        assert abs(got["abs"] - chk["abs"]) < 1e-5 * scale, name
     for nm, arr in (("embracenet.docking_0.weight", "_g_dock0_w"), ("embracenet.docking_0.bias", "_g_dock0_b"),
                     ("embracenet.docking_1.bias", "_g_dock1_b")):
         ref = g[key + arr]
