@@ -128,6 +128,37 @@ int emb_nadam_step(void* param, const void* grad, void* exp_avg, void* exp_avg_s
                    double weight_decay, double schedule_decay, uint64_t step_val, const uint64_t* step_dev,
                    int dtype, emb_stream_t stream);
 
+/* ---- sequence pre-network; activations channels-last x[B][L][C] --------------------------
+ * One block of CNN_pre.py:37-50: Conv1d(k odd, stride 1, same padding) -> BatchNorm1d -> ReLU ->
+ * MaxPool1d(10, 2) [-> Dropout].  cin_pad = input channels rounded up to the 16-byte vector (zero channels).
+ *   emb_ncl_to_nlc        x[B][C][L] (reference loader layout, dataprepare.py:398-412) -> out[B][L][Cpad] T
+ *   emb_conv_pack_weight  nn.Conv1d weight W[Cout][Cin][k] P -> wpack[Cout][k*cin_pad] T (tap-major) and,
+ *                         when wflip != NULL, wflip[cin_pad][k*Cout] T (flipped taps, for the input gradient)
+ *   emb_convblock_workspace_bytes  scratch the two calls below need (caller allocates; contents are transient)
+ *   emb_convblock_fwd     y[B][L][Cout] T = conv + bias (kept for backward); stats[4][Cout] P = mean, invstd,
+ *                         scale, shift (batch statistics when training != 0, running statistics otherwise;
+ *                         running_mean/var updated with `momentum` as nn.BatchNorm1d does);
+ *                         out = dropout(maxpool(relu(bn(y)))) as [B][Lp][Cout] or, out_ncl != 0, [B][Cout][Lp]
+ *                         (the flatten order of CNN_pre.py:74); argmax[B][Lp][Cout] u8 (bits 0-3 window
+ *                         offset of the maximum, bit 7 dropped).  Dropout mask: RNG kind 16+layer_id.
+ *   emb_convblock_bwd     dout (layout as `out`) -> dx[B][L][cin_pad] T (nullable), dW[Cout][Cin][k] P (torch
+ *                         layout), dbias, dgamma, dbeta [Cout] P; dy[B][L][Cout] T is caller-provided scratch. */
+int64_t emb_convblock_workspace_bytes(int B, int L, int cin_pad, int Cout, int k, int dtype);
+int emb_ncl_to_nlc(const void* x, int src_dtype, void* out, int dst_dtype, int B, int C, int L, int Cpad,
+                   emb_stream_t stream);
+int emb_conv_pack_weight(const void* W, void* wpack, void* wflip, int Cout, int Cin, int cin_pad, int k, int dtype,
+                         emb_stream_t stream);
+int emb_convblock_fwd(const void* x, const void* wpack, const void* bias, const void* gamma, const void* beta,
+                      void* running_mean, void* running_var, int training, double momentum, double eps,
+                      float dropout_p, uint64_t seed, uint64_t step_val, const uint64_t* step_dev, int64_t row0,
+                      int layer_id, void* y, void* stats, void* out, uint8_t* argmax, int out_ncl, void* workspace,
+                      int64_t workspace_bytes, int B, int L, int cin_pad, int Cout, int k, int dtype,
+                      emb_stream_t stream);
+int emb_convblock_bwd(const void* dout, int dout_ncl, const uint8_t* argmax, const void* y, const void* stats,
+                      const void* x, const void* wflip, float dropout_p, int training, void* dx, void* dW,
+                      void* dbias, void* dgamma, void* dbeta, void* dy, void* workspace, int64_t workspace_bytes,
+                      int B, int L, int Cin, int cin_pad, int Cout, int k, int dtype, emb_stream_t stream);
+
 /* helpers: dtype conversion (fp32/fp64 master -> bf16 shadow etc.) and a device step counter */
 int emb_cast(const void* src, int src_dtype, void* dst, int dst_dtype, int64_t n, emb_stream_t stream);
 int emb_counter_add(uint64_t* counter, uint64_t inc, emb_stream_t stream);

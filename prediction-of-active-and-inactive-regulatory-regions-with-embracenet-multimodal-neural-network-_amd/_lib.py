@@ -38,6 +38,12 @@ SIGNATURES = {
     "emb_adam_step": [_vp] * 5 + [_i64, _d, _d, _d, _d, _d, _u64, _vp, _i, _vp],
     "emb_rmsprop_step": [_vp] * 4 + [_i64, _d, _d, _d, _d, _i, _vp],
     "emb_nadam_step": [_vp] * 6 + [_i64, _d, _d, _d, _d, _d, _d, _u64, _vp, _i, _vp],
+    "emb_convblock_workspace_bytes": [_i, _i, _i, _i, _i, _i],
+    "emb_ncl_to_nlc": [_vp, _i, _vp, _i, _i, _i, _i, _i, _vp],
+    "emb_conv_pack_weight": [_vp, _vp, _vp, _i, _i, _i, _i, _i, _vp],
+    "emb_convblock_fwd": [_vp] * 7 + [_i, _d, _d, _f, _u64, _u64, _vp, _i64, _i, _vp, _vp, _vp, _vp, _i, _vp, _i64,
+                                     _i, _i, _i, _i, _i, _i, _vp],
+    "emb_convblock_bwd": [_vp, _i, _vp, _vp, _vp, _vp, _vp, _f, _i] + [_vp] * 7 + [_i64, _i, _i, _i, _i, _i, _i, _i, _vp],
     "emb_cast": [_vp, _i, _vp, _i, _i64, _vp],
     "emb_counter_add": [_vp, _u64, _vp],
 }
@@ -67,7 +73,8 @@ def lib():
         for name, argtypes in SIGNATURES.items():
             fn = getattr(L, name)
             fn.argtypes = argtypes
-            fn.restype = ctypes.c_char_p if name == "emb_last_error" else ctypes.c_int
+            fn.restype = {"emb_last_error": ctypes.c_char_p,
+                          "emb_convblock_workspace_bytes": ctypes.c_int64}.get(name, ctypes.c_int)
         if L.emb_abi_version() != 1:
             raise RuntimeError("libembrace_hip.so ABI version mismatch")
         _lib = L

@@ -1,0 +1,703 @@
+// One block of the sequence pre-network: Conv1d(same padding) -> BatchNorm1d -> ReLU -> MaxPool1d(10, 2)
+// [-> Dropout], forward and backward.  Reference: BIOINF_tesi/models/CNN_pre.py:37-50 (83 % of the
+// model's FLOPs).
+//
+// Activations are channels-last ("NLC", x[b][t][c]).  With that layout the im2col matrix of a same-padded
+// 1-D convolution is a plain strided VIEW of x: row R = b*L + t, column KK = tap*cin + ci lives at
+// x + (R - pad)*cin + KK, and only validity (0 <= t - pad + tap < L) has to be checked.  So the three
+// contractions of a block are ordinary MFMA GEMMs on the shared tile core (gemm_core.h), no im2col buffer:
+//   forward   y[R, Cout]   = view(x)[R, k*cin]      . wpack[Cout, k*cin]^T       (+ bias, + BN partial sums)
+//   dgrad     dx[R, cin]   = view(dy)[R, k*Cout]    . wflip[cin, k*Cout]^T       (taps flipped)
+//   wgrad     dW[Cout, k*cin] = dy^T[Cout, R]       . view(x)^T[k*cin, R]        (split over R, fixed-order reduce)
+// BatchNorm batch statistics come from per-tile partial sums written by the forward GEMM's epilogue and are
+// finalised in double; BN + ReLU + max-pool (+ dropout) is one elementwise pass; the backward recomputes the
+// pooled gradient by a deterministic gather (no atomics anywhere: results are bitwise reproducible).
+#include "gemm_tile.h"
+
+namespace emb {
+
+template <typename T> struct ConvCfg;
+template <> struct ConvCfg<__bf16> {
+  using F64 = TileCfg<__bf16, 128, 64, 64, 4, 1, 1, false, false>;
+  using F32 = TileCfg<__bf16, 128, 32, 64, 4, 1, 1, false, false>;
+  using W = TileCfg<__bf16, 64, 64, 64, 2, 2, 1, true, true>;
+};
+template <> struct ConvCfg<float> {
+  using F64 = TileCfg<float, 128, 64, 32, 4, 1, 1, false, false>;
+  using F32 = TileCfg<float, 128, 32, 32, 4, 1, 1, false, false>;
+  using W = TileCfg<float, 64, 64, 32, 2, 2, 1, true, true>;
+};
+template <> struct ConvCfg<double> {
+  using F64 = TileCfg<double, 128, 64, 16, 4, 1, 1, false, false>;
+  using F32 = TileCfg<double, 128, 32, 16, 4, 1, 1, false, false>;
+  using W = TileCfg<double, 64, 64, 16, 2, 2, 1, true, true>;
+};
+
+constexpr int kPoolK = 10, kPoolS = 2;   // CNN_pre.py:17,19
+
+// ------------------------------------------------------------------------------------ conv GEMM
+// FWD: C = view(x).wpack^T + bias, per-tile column sums of C and C^2 -> partial[tm][2][N].   !FWD: plain store.
+template <class Cfg, bool FWD>
+__global__ __launch_bounds__(kThreads) void conv_gemm_kernel(const typename Cfg::T* __restrict__ x,
+                                                             const typename Cfg::T* __restrict__ w,
+                                                             const typename Cfg::M::Acc* __restrict__ bias,
+                                                             typename Cfg::T* __restrict__ out,
+                                                             typename Cfg::M::Acc* __restrict__ partial, int R, int L, int cin,
+                                                             int KK, int N, int pad, int tiles_n, int ntiles, int vec_x,
+                                                             int vec_w, int vec_o) {
+  using T = typename Cfg::T;
+  using Mm = typename Cfg::M;
+  using Acc = typename Mm::Acc;
+  extern __shared__ __attribute__((aligned(16))) char arena[];
+  const int tile = xcd_remap(blockIdx.x, ntiles);
+  const int tm = tile / tiles_n, tn = tile % tiles_n;
+  const int row0 = tm * Cfg::BM, col0 = tn * Cfg::BN;
+  typename Mm::AccV acc[Cfg::MI][Cfg::NI];
+  zero_acc<Cfg>(acc);
+  Stager<T, false, Cfg::BM, Cfg::BK, XfNone> sa{x, nullptr, cin, row0, R, KK, vec_x != 0, XfNone{}, -1, L, cin, pad};
+  Stager<T, false, Cfg::BN, Cfg::BK, XfNone> sb{w, nullptr, KK, col0, N, KK, vec_w != 0, XfNone{}, -1, 0, 0, 0};
+  gemm_mainloop<Cfg>(sa, sb, KK, arena, acc);
+  Acc* cs = reinterpret_cast<Acc*>(arena);
+  reduce_to_slab<Cfg>(acc, cs);
+  constexpr int GROUPS = Cfg::BM * Cfg::BN / 4;
+  for (int gidx = threadIdx.x; gidx < GROUPS; gidx += kThreads) {
+    const int r = gidx / (Cfg::BN / 4), cq = (gidx % (Cfg::BN / 4)) * 4;
+    const int row = row0 + r, col = col0 + cq;
+    Acc v[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      v[j] = cs[r * Cfg::CS + cq + j];
+      if (FWD) {
+        v[j] += bias[min(col + j, N - 1)];
+        cs[r * Cfg::CS + cq + j] = (row < R && col + j < N) ? v[j] : (Acc)0;   // what the statistics pass sums
+      }
+    }
+    if (row >= R || col >= N) continue;
+    T* dst = out + (long)row * N + col;
+    if (col + 4 <= N && vec_o) {
+      typedef T TV4 __attribute__((ext_vector_type(4)));
+      TV4 o = {(T)v[0], (T)v[1], (T)v[2], (T)v[3]};
+      *reinterpret_cast<TV4*>(dst) = o;
+    } else {
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+        if (col + j < N) dst[j] = (T)v[j];
+    }
+  }
+  if (FWD) {
+    __syncthreads();
+    // column sums over the tile's rows: thread (part, col) sums rows part, part+PARTS, ...; parts combined in order
+    constexpr int PARTS = kThreads / Cfg::BN;
+    Acc* red = cs + Cfg::SLAB;   // [2][PARTS][BN]
+    const int colr = threadIdx.x % Cfg::BN, part = threadIdx.x / Cfg::BN;
+    Acc s = 0, s2 = 0;
+    for (int r = part; r < Cfg::BM; r += PARTS) {
+      const Acc v = cs[r * Cfg::CS + colr];
+      s += v;
+      s2 += v * v;
+    }
+    red[part * Cfg::BN + colr] = s;
+    red[(PARTS + part) * Cfg::BN + colr] = s2;
+    __syncthreads();
+    if (part == 0 && col0 + colr < N) {
+      Acc a = 0, b = 0;
+      for (int p = 0; p < PARTS; ++p) {
+        a += red[p * Cfg::BN + colr];
+        b += red[(PARTS + p) * Cfg::BN + colr];
+      }
+      partial[((long)tm * 2 + 0) * N + col0 + colr] = a;
+      partial[((long)tm * 2 + 1) * N + col0 + colr] = b;
+    }
+  }
+}
+
+template <class Cfg> constexpr int conv_gemm_lds() {
+  constexpr int slab = (Cfg::SLAB + 2 * kThreads) * (int)sizeof(typename Cfg::M::Acc);
+  return Cfg::OPERAND_BYTES > slab ? Cfg::OPERAND_BYTES : slab;
+}
+
+template <class Cfg, bool FWD>
+static int launch_conv_gemm(const void* x, const void* w, const void* bias, void* out, void* partial, int R, int L, int cin,
+                            int KK, int N, int pad, hipStream_t s) {
+  using T = typename Cfg::T;
+  using Acc = typename Cfg::M::Acc;
+  constexpr int VEC = Elem<T>::VEC;
+  const int tiles_n = cdiv(N, Cfg::BN), ntiles = cdiv(R, Cfg::BM) * tiles_n;
+  const int vec_x = (cin % VEC == 0) && aligned16(x), vec_w = (KK % VEC == 0) && aligned16(w);
+  const int vec_o = (N % 4 == 0) && aligned16(out);
+  constexpr int lds = conv_gemm_lds<Cfg>();
+  static bool attr_set = false;
+  if (!attr_set && lds > 48 * 1024) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_gemm_kernel<Cfg, FWD>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    attr_set = true;
+  }
+  conv_gemm_kernel<Cfg, FWD><<<ntiles, kThreads, lds, s>>>((const T*)x, (const T*)w, (const Acc*)bias, (T*)out, (Acc*)partial, R,
+                                                         L, cin, KK, N, pad, tiles_n, ntiles, vec_x, vec_w, vec_o);
+  EMB_CHECK_LAUNCH();
+  return EMB_OK;
+}
+
+// ------------------------------------------------------------------------------- BN statistics
+// stats[0..3][C] = mean, invstd, scale = gamma*invstd, shift = beta - mean*scale   (P-typed)
+template <typename P>
+__global__ __launch_bounds__(256) void bn_finalize_kernel(const P* __restrict__ partial, int tiles_m, int C, double count,
+                                                          const P* __restrict__ gamma, const P* __restrict__ beta,
+                                                          P* __restrict__ running_mean, P* __restrict__ running_var,
+                                                          int training, double momentum, double eps, P* __restrict__ stats) {
+  __shared__ double sa[256], sb[256];
+  const int c = blockIdx.x, tid = threadIdx.x;
+  double mean, var;
+  if (training) {
+    double a = 0, b = 0;
+    for (int t = tid; t < tiles_m; t += 256) {
+      a += (double)partial[((long)t * 2 + 0) * C + c];
+      b += (double)partial[((long)t * 2 + 1) * C + c];
+    }
+    sa[tid] = a;
+    sb[tid] = b;
+    __syncthreads();
+    for (int s = 128; s > 0; s >>= 1) {
+      if (tid < s) {
+        sa[tid] += sa[tid + s];
+        sb[tid] += sb[tid + s];
+      }
+      __syncthreads();
+    }
+    mean = sa[0] / count;
+    var = sb[0] / count - mean * mean;   // biased variance (normalisation); double keeps the cancellation benign
+    if (var < 0) var = 0;
+  } else {
+    mean = (double)running_mean[c];
+    var = (double)running_var[c];
+  }
+  if (tid == 0) {
+    const double invstd = 1.0 / sqrt(var + eps);
+    const double scale = (double)gamma[c] * invstd;
+    stats[c] = (P)mean;
+    stats[C + c] = (P)invstd;
+    stats[2 * C + c] = (P)scale;
+    stats[3 * C + c] = (P)((double)beta[c] - mean * scale);
+    if (training) {   // nn.BatchNorm1d: running_var uses the unbiased estimate
+      const double unbiased = count > 1 ? var * count / (count - 1.0) : var;
+      running_mean[c] = (P)((1.0 - momentum) * (double)running_mean[c] + momentum * mean);
+      running_var[c] = (P)((1.0 - momentum) * (double)running_var[c] + momentum * unbiased);
+    }
+  }
+}
+
+// ---------------------------------------------------------------------- BN + ReLU + MaxPool (+ Dropout)
+// argmax byte: bits 0-3 = offset of the maximum inside the window (first maximum wins, as torch), bit 7 = dropped.
+template <typename T, bool NCL_OUT>
+__global__ __launch_bounds__(256) void bn_relu_pool_kernel(const T* __restrict__ y, const typename AccOf<T>::type* __restrict__ stats,
+                                                           T* __restrict__ out, uint8_t* __restrict__ argmax, int B, int L,
+                                                           int Lp, int C, float drop_p, uint64_t seed, uint64_t step_val,
+                                                           const uint64_t* __restrict__ step_dev, int64_t grow0, int layer_id) {
+  using Acc = typename AccOf<T>::type;
+  constexpr int VEC = Elem<T>::VEC;
+  using V = typename Vec16<T>::type;
+  const int cv = C / VEC;
+  const long total = (long)B * Lp * cv;
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= total) return;
+  const int c0 = (int)(i % cv) * VEC;
+  const int p = (int)((i / cv) % Lp);
+  const int b = (int)(i / ((long)cv * Lp));
+  Acc sc[VEC], sh[VEC], best[VEC];
+  int arg[VEC];
+#pragma unroll
+  for (int e = 0; e < VEC; ++e) {
+    sc[e] = stats[2 * C + c0 + e];
+    sh[e] = stats[3 * C + c0 + e];
+    best[e] = (Acc)-1;   // post-ReLU values are >= 0
+    arg[e] = 0;
+  }
+  const T* base = y + ((long)b * L + (long)p * kPoolS) * C + c0;
+#pragma unroll
+  for (int w = 0; w < kPoolK; ++w) {
+    const V v = *reinterpret_cast<const V*>(base + (long)w * C);
+#pragma unroll
+    for (int e = 0; e < VEC; ++e) {
+      Acc z = (Acc)v[e] * sc[e] + sh[e];
+      z = z > (Acc)0 ? z : (Acc)0;
+      if (z > best[e]) {
+        best[e] = z;
+        arg[e] = w;
+      }
+    }
+  }
+  float keep_scale = 1.0f;
+  uint64_t stream = 0;
+  if (drop_p > 0.0f) {
+    keep_scale = 1.0f / (1.0f - drop_p);
+    stream = rng_stream(step_val + (step_dev ? *step_dev : 0), EMB_RNG_DROPOUT0 + layer_id);
+  }
+  uint64_t am = 0;
+  V o;
+#pragma unroll
+  for (int e = 0; e < VEC; ++e) {
+    Acc z = best[e];
+    int a = arg[e];
+    if (drop_p > 0.0f) {
+      const uint64_t idx = ((uint64_t)(grow0 + b) * Lp + p) * C + c0 + e;
+      const bool keep = uniform24(philox4x32_10(seed, stream, idx).x) >= drop_p;
+      z = keep ? z * (Acc)keep_scale : (Acc)0;
+      a |= keep ? 0 : 0x80;
+    }
+    o[e] = (T)z;
+    am |= (uint64_t)(uint8_t)a << (8 * e);
+  }
+  const long nlc = ((long)b * Lp + p) * C + c0;
+  if (VEC == 8) *reinterpret_cast<uint64_t*>(argmax + nlc) = am;
+  else if (VEC == 4) *reinterpret_cast<uint32_t*>(argmax + nlc) = (uint32_t)am;
+  else *reinterpret_cast<uint16_t*>(argmax + nlc) = (uint16_t)am;
+  if (NCL_OUT) {   // last block: the reference flattens [B, C, Lp] (CNN_pre.py:74), channel-major
+#pragma unroll
+    for (int e = 0; e < VEC; ++e) out[((long)b * C + c0 + e) * Lp + p] = o[e];
+  } else {
+    *reinterpret_cast<V*>(out + nlc) = o;
+  }
+}
+
+// gradient reaching the BN output at (b, t, c0..c0+VEC): gather over the <= 5 pooling windows that contain t
+template <typename T, bool NCL_IN>
+__device__ __forceinline__ void gather_dz(const T* __restrict__ dout, const uint8_t* __restrict__ argmax, int b, int t, int c0,
+                                          int Lp, int C, float keep_scale, typename AccOf<T>::type (&dz)[Elem<T>::VEC]) {
+  using Acc = typename AccOf<T>::type;
+  constexpr int VEC = Elem<T>::VEC;
+  using V = typename Vec16<T>::type;
+#pragma unroll
+  for (int e = 0; e < VEC; ++e) dz[e] = 0;
+  const int p_lo = t >= kPoolK - 1 ? (t - (kPoolK - 1) + 1) / 2 : 0;
+  const int p_hi = min(Lp - 1, t / 2);
+  for (int p = p_lo; p <= p_hi; ++p) {
+    const int off = t - kPoolS * p;
+    const long nlc = ((long)b * Lp + p) * C + c0;
+    uint64_t am;
+    if (VEC == 8) am = *reinterpret_cast<const uint64_t*>(argmax + nlc);
+    else if (VEC == 4) am = *reinterpret_cast<const uint32_t*>(argmax + nlc);
+    else am = *reinterpret_cast<const uint16_t*>(argmax + nlc);
+    V g;
+    if (NCL_IN) {
+#pragma unroll
+      for (int e = 0; e < VEC; ++e) g[e] = dout[((long)b * C + c0 + e) * Lp + p];
+    } else {
+      g = *reinterpret_cast<const V*>(dout + nlc);
+    }
+#pragma unroll
+    for (int e = 0; e < VEC; ++e) {
+      const int a = (int)((am >> (8 * e)) & 0xFF);
+      if (a == off) dz[e] += (Acc)g[e] * (Acc)keep_scale;   // dropped entries carry bit 7 -> never equal to off
+    }
+  }
+}
+
+// pass 1 of BatchNorm backward: per-block partial sums of dz and dz * xhat  -> bpart[blk][2][C]
+template <typename T, bool NCL_IN>
+__global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const T* __restrict__ dout, const uint8_t* __restrict__ argmax,
+                                                            const T* __restrict__ y, const typename AccOf<T>::type* __restrict__ stats,
+                                                            typename AccOf<T>::type* __restrict__ bpart, int B, int L, int Lp, int C,
+                                                            float keep_scale, int rows_per_block) {
+  using Acc = typename AccOf<T>::type;
+  constexpr int VEC = Elem<T>::VEC;
+  using V = typename Vec16<T>::type;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  Acc* red = reinterpret_cast<Acc*>(smem);   // [TY][2][C]
+  const int TX = C / VEC, TY = 256 / TX;
+  const int tx = threadIdx.x % TX, ty = threadIdx.x / TX;
+  const int c0 = tx * VEC;
+  const long R = (long)B * L;
+  Acc s1[VEC], s2[VEC], mean[VEC], inv[VEC], sc[VEC], sh[VEC];
+#pragma unroll
+  for (int e = 0; e < VEC; ++e) {
+    s1[e] = 0; s2[e] = 0;
+    mean[e] = stats[c0 + e]; inv[e] = stats[C + c0 + e]; sc[e] = stats[2 * C + c0 + e]; sh[e] = stats[3 * C + c0 + e];
+  }
+  if (ty < TY) {
+    const long r_begin = (long)blockIdx.x * rows_per_block;
+    for (long r = r_begin + ty; r < r_begin + rows_per_block && r < R; r += TY) {
+      const int b = (int)(r / L), t = (int)(r % L);
+      Acc dz[VEC];
+      gather_dz<T, NCL_IN>(dout, argmax, b, t, c0, Lp, C, keep_scale, dz);
+      const V yv = *reinterpret_cast<const V*>(y + r * C + c0);
+#pragma unroll
+      for (int e = 0; e < VEC; ++e) {
+        const Acc yy = (Acc)yv[e];
+        const Acc g = (yy * sc[e] + sh[e]) > (Acc)0 ? dz[e] : (Acc)0;   // ReLU mask
+        s1[e] += g;
+        s2[e] += g * ((yy - mean[e]) * inv[e]);
+      }
+    }
+#pragma unroll
+    for (int e = 0; e < VEC; ++e) {
+      red[((long)ty * 2 + 0) * C + c0 + e] = s1[e];
+      red[((long)ty * 2 + 1) * C + c0 + e] = s2[e];
+    }
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < 2 * C; i += 256) {
+    Acc a = 0;
+    for (int q = 0; q < TY; ++q) a += red[(long)q * 2 * C + i];
+    bpart[(long)blockIdx.x * 2 * C + i] = a;
+  }
+}
+
+// finalise dgamma / dbeta and the two per-channel means the apply pass needs: coef[0][c] = mean(dz), coef[1][c] = mean(dz*xhat)
+template <typename P>
+__global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(const P* __restrict__ bpart, int nblk, int C, double count,
+                                                              P* __restrict__ dgamma, P* __restrict__ dbeta, P* __restrict__ coef) {
+  __shared__ double sa[256], sb[256];
+  const int c = blockIdx.x, tid = threadIdx.x;
+  double a = 0, b = 0;
+  for (int t = tid; t < nblk; t += 256) {
+    a += (double)bpart[((long)t * 2 + 0) * C + c];
+    b += (double)bpart[((long)t * 2 + 1) * C + c];
+  }
+  sa[tid] = a;
+  sb[tid] = b;
+  __syncthreads();
+  for (int s = 128; s > 0; s >>= 1) {
+    if (tid < s) {
+      sa[tid] += sa[tid + s];
+      sb[tid] += sb[tid + s];
+    }
+    __syncthreads();
+  }
+  if (tid == 0) {
+    dbeta[c] = (P)sa[0];
+    dgamma[c] = (P)sb[0];
+    coef[c] = (P)(sa[0] / count);
+    coef[C + c] = (P)(sb[0] / count);
+  }
+}
+
+// pass 2: dy = scale * (dz - mean(dz) - xhat * mean(dz*xhat))   (training);   dy = scale * dz   (eval)
+template <typename T, bool NCL_IN>
+__global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const T* __restrict__ dout, const uint8_t* __restrict__ argmax,
+                                                           const T* __restrict__ y, const typename AccOf<T>::type* __restrict__ stats,
+                                                           const typename AccOf<T>::type* __restrict__ coef, T* __restrict__ dy,
+                                                           int B, int L, int Lp, int C, float keep_scale, int training) {
+  using Acc = typename AccOf<T>::type;
+  constexpr int VEC = Elem<T>::VEC;
+  using V = typename Vec16<T>::type;
+  const int cv = C / VEC;
+  const long total = (long)B * L * cv;
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= total) return;
+  const int c0 = (int)(i % cv) * VEC;
+  const long r = i / cv;
+  const int b = (int)(r / L), t = (int)(r % L);
+  Acc dz[VEC];
+  gather_dz<T, NCL_IN>(dout, argmax, b, t, c0, Lp, C, keep_scale, dz);
+  const V yv = *reinterpret_cast<const V*>(y + r * C + c0);
+  V o;
+#pragma unroll
+  for (int e = 0; e < VEC; ++e) {
+    const Acc yy = (Acc)yv[e];
+    const Acc sc = stats[2 * C + c0 + e], sh = stats[3 * C + c0 + e];
+    const Acc g = (yy * sc + sh) > (Acc)0 ? dz[e] : (Acc)0;
+    Acc d = g;
+    if (training) d = g - coef[c0 + e] - ((yy - stats[c0 + e]) * stats[C + c0 + e]) * coef[C + c0 + e];
+    o[e] = (T)(sc * d);
+  }
+  *reinterpret_cast<V*>(dy + r * C + c0) = o;
+}
+
+// ------------------------------------------------------------------------------------- wgrad
+// slab[s][Cout][KK+1] = dy^T . [view(x) | 1] over rows [s*kper, (s+1)*kper)
+template <class Cfg>
+__global__ __launch_bounds__(kThreads) void conv_wgrad_kernel(const typename Cfg::T* __restrict__ dy,
+                                                              const typename Cfg::T* __restrict__ x,
+                                                              typename Cfg::M::Acc* __restrict__ slab, int R, int L, int cin,
+                                                              int KK, int Cout, int pad, int kper, int tiles_n, int tiles_per_slice,
+                                                              int vec_dy, int vec_x) {
+  using T = typename Cfg::T;
+  using Acc = typename Cfg::M::Acc;
+  extern __shared__ __attribute__((aligned(16))) char arena[];
+  const int s = blockIdx.x / tiles_per_slice;
+  const int tile = xcd_remap(blockIdx.x % tiles_per_slice, tiles_per_slice);
+  const int k_begin = s * kper, k_end = min(R, k_begin + kper);
+  GemmOperand<T> A{dy, nullptr, Cout, vec_dy != 0};
+  const int row0 = (tile / tiles_n) * Cfg::BM, col0 = (tile % tiles_n) * Cfg::BN;
+  typename Cfg::M::AccV acc[Cfg::MI][Cfg::NI];
+  zero_acc<Cfg>(acc);
+  Stager<T, true, Cfg::BM, Cfg::BK, XfNone> sa{A.ptr, nullptr, Cout, row0, Cout, k_end, A.vec_ok, XfNone{}, -1, 0, 0, 0};
+  Stager<T, true, Cfg::BN, Cfg::BK, XfNone> sb{x, nullptr, cin, col0, KK, k_end, vec_x != 0, XfNone{}, KK, L, cin, pad};
+  gemm_mainloop<Cfg>(sa, sb, k_end, arena, acc, k_begin);
+  Acc* cs = reinterpret_cast<Acc*>(arena);
+  reduce_to_slab<Cfg>(acc, cs);
+  Acc* dst = slab + (long)s * Cout * (KK + 1);
+  for (int i = threadIdx.x; i < Cfg::BM * Cfg::BN; i += kThreads) {
+    const int r = i / Cfg::BN, c = i % Cfg::BN;
+    if (row0 + r < Cout && col0 + c <= KK) dst[(long)(row0 + r) * (KK + 1) + col0 + c] = cs[r * Cfg::CS + c];
+  }
+}
+
+// dW[o][ci][j] (torch Conv1d layout, real channels only) and dbias[o] from the slabs, slices summed in order
+template <typename P>
+__global__ void conv_wgrad_reduce_kernel(const P* __restrict__ slab, int S, int Cout, int Cin, int cin_pad, int k,
+                                         P* __restrict__ dW, P* __restrict__ dbias) {
+  const int KK = k * cin_pad;
+  const long n_w = (long)Cout * Cin * k;
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n_w + Cout) return;
+  long src;
+  if (i < n_w) {
+    const int j = (int)(i % k), ci = (int)((i / k) % Cin), o = (int)(i / ((long)k * Cin));
+    src = (long)o * (KK + 1) + (long)j * cin_pad + ci;
+  } else {
+    src = (long)(i - n_w) * (KK + 1) + KK;
+  }
+  P a = 0;
+  for (int s = 0; s < S; ++s) a += slab[(long)s * Cout * (KK + 1) + src];
+  if (i < n_w) dW[i] = a;
+  else dbias[i - n_w] = a;
+}
+
+// ------------------------------------------------------------------------------ layout helpers
+// W[Cout][Cin][k] (P) -> wpack[Cout][k*cin_pad] (T, tap-major, zero padded channels)
+//                     -> wflip[cin_pad][k*Cout]  (T, wflip[ci][j*Cout + o] = W[o][ci][k-1-j])
+template <typename P, typename T>
+__global__ void conv_pack_weight_kernel(const P* __restrict__ W, T* __restrict__ wpack, T* __restrict__ wflip, int Cout, int Cin,
+                                        int cin_pad, int k) {
+  const long n1 = (long)Cout * k * cin_pad, n2 = (long)cin_pad * k * Cout;
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n1) {
+    const int ci = (int)(i % cin_pad), j = (int)((i / cin_pad) % k), o = (int)(i / ((long)cin_pad * k));
+    wpack[i] = ci < Cin ? (T)(typename AccOf<T>::type)W[((long)o * Cin + ci) * k + j] : (T)0.0f;
+  } else if (i < n1 + n2 && wflip != nullptr) {
+    const long q = i - n1;
+    const int o = (int)(q % Cout), j = (int)((q / Cout) % k), ci = (int)(q / ((long)Cout * k));
+    wflip[q] = ci < Cin ? (T)(typename AccOf<T>::type)W[((long)o * Cin + ci) * k + (k - 1 - j)] : (T)0.0f;
+  }
+}
+
+// x[B][C][L] (any float type) -> out[B][L][Cpad] (T), zero padded channels
+template <typename S, typename T>
+__global__ void ncl_to_nlc_kernel(const S* __restrict__ x, T* __restrict__ out, int B, int C, int L, int Cpad) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;   // over B*L
+  if (i >= (long)B * L) return;
+  const int t = (int)(i % L);
+  const long b = i / L;
+  for (int c = 0; c < Cpad; ++c)
+    out[i * Cpad + c] = c < C ? (T)(typename AccOf<T>::type)(typename AccOf<S>::type)x[(b * C + c) * L + t] : (T)0.0f;
+}
+
+// ------------------------------------------------------------------------------- host plumbing
+struct ConvWs {
+  size_t stat_partial, bwd_partial, coef, slab, total;
+  int tiles_m, nblk_bwd, rows_per_block, S, kper;
+};
+
+template <typename T> static ConvWs conv_workspace(int B, int L, int cin_pad, int Cout, int k) {
+  using P = typename AccOf<T>::type;
+  using CF = typename ConvCfg<T>::F64;
+  using CW = typename ConvCfg<T>::W;
+  constexpr int VEC = Elem<T>::VEC;
+  ConvWs w;
+  const long R = (long)B * L;
+  const int KK = k * cin_pad;
+  w.tiles_m = cdiv((int)R, CF::BM);
+  const int TX = Cout / VEC, TY = 256 / (TX > 0 ? TX : 1);
+  w.rows_per_block = TY * 8;
+  w.nblk_bwd = cdiv((int)R, w.rows_per_block);
+  const int tiles = cdiv(Cout, CW::BM) * cdiv(KK + 1, CW::BN);
+  int S = 1024 / (tiles > 0 ? tiles : 1);
+  const int max_s = (int)(R / (4 * CW::BK));
+  if (S > max_s) S = max_s;
+  if (S < 1) S = 1;
+  int kper = cdiv((int)R, S);
+  kper = cdiv(kper, CW::BK) * CW::BK;
+  S = cdiv((int)R, kper);
+  w.S = S;
+  w.kper = kper;
+  auto al = [](size_t b) { return (b + 255) & ~(size_t)255; };
+  w.stat_partial = al((size_t)w.tiles_m * 2 * Cout * sizeof(P));
+  w.bwd_partial = al((size_t)w.nblk_bwd * 2 * Cout * sizeof(P));
+  w.coef = al((size_t)2 * Cout * sizeof(P));
+  w.slab = al((size_t)S * Cout * (KK + 1) * sizeof(P));
+  const size_t fwd = w.stat_partial, bwd = w.bwd_partial + w.coef + w.slab;
+  w.total = fwd > bwd ? fwd : bwd;
+  return w;
+}
+
+template <typename T>
+static int convblock_fwd(const void* x, const void* wpack, const void* bias, const void* gamma, const void* beta, void* rmean,
+                         void* rvar, int training, double momentum, double eps, float drop_p, uint64_t seed, uint64_t step_val,
+                         const uint64_t* step_dev, int64_t row0, int layer_id, void* y, void* stats, void* out, uint8_t* argmax,
+                         int out_ncl, void* ws, int64_t ws_bytes, int B, int L, int cin_pad, int Cout, int k, hipStream_t s) {
+  using P = typename AccOf<T>::type;
+  constexpr int VEC = Elem<T>::VEC;
+  const ConvWs w = conv_workspace<T>(B, L, cin_pad, Cout, k);
+  EMB_CHECK_ARG((size_t)ws_bytes >= w.total, "emb_convblock_fwd: workspace too small (%lld < %zu)", (long long)ws_bytes, w.total);
+  EMB_CHECK_ARG(cin_pad % VEC == 0 && Cout % VEC == 0, "emb_convblock_fwd: channels must be multiples of %d", VEC);
+  const int R = B * L, KK = k * cin_pad, pad = (k - 1) / 2, Lp = (L - kPoolK) / kPoolS + 1;
+  EMB_CHECK_ARG(Lp >= 1, "emb_convblock_fwd: sequence too short for the pooling window");
+  int rc;
+  if (Cout >= 64) rc = launch_conv_gemm<typename ConvCfg<T>::F64, true>(x, wpack, bias, y, ws, R, L, cin_pad, KK, Cout, pad, s);
+  else rc = launch_conv_gemm<typename ConvCfg<T>::F32, true>(x, wpack, bias, y, ws, R, L, cin_pad, KK, Cout, pad, s);
+  if (rc != EMB_OK) return rc;
+  const int tiles_m = cdiv(R, Cout >= 64 ? ConvCfg<T>::F64::BM : ConvCfg<T>::F32::BM);
+  bn_finalize_kernel<P><<<Cout, 256, 0, s>>>((const P*)ws, tiles_m, Cout, (double)R, (const P*)gamma, (const P*)beta, (P*)rmean,
+                                           (P*)rvar, training, momentum, eps, (P*)stats);
+  EMB_CHECK_LAUNCH();
+  const long total = (long)B * Lp * (Cout / VEC);
+  const int grid = (int)((total + 255) / 256);
+  if (out_ncl)
+    bn_relu_pool_kernel<T, true><<<grid, 256, 0, s>>>((const T*)y, (const P*)stats, (T*)out, argmax, B, L, Lp, Cout, drop_p, seed, step_val, step_dev, row0, layer_id);
+  else
+    bn_relu_pool_kernel<T, false><<<grid, 256, 0, s>>>((const T*)y, (const P*)stats, (T*)out, argmax, B, L, Lp, Cout, drop_p, seed, step_val, step_dev, row0, layer_id);
+  EMB_CHECK_LAUNCH();
+  return EMB_OK;
+}
+
+template <typename T>
+static int convblock_bwd(const void* dout, int dout_ncl, const uint8_t* argmax, const void* y, const void* stats, const void* x,
+                         const void* wflip, float drop_p, int training, void* dx, void* dW, void* dbias, void* dgamma, void* dbeta,
+                         void* dy, void* ws, int64_t ws_bytes, int B, int L, int Cin, int cin_pad, int Cout, int k, hipStream_t s) {
+  using P = typename AccOf<T>::type;
+  using CW = typename ConvCfg<T>::W;
+  constexpr int VEC = Elem<T>::VEC;
+  const ConvWs w = conv_workspace<T>(B, L, cin_pad, Cout, k);
+  EMB_CHECK_ARG((size_t)ws_bytes >= w.total, "emb_convblock_bwd: workspace too small (%lld < %zu)", (long long)ws_bytes, w.total);
+  const int R = B * L, KK = k * cin_pad, pad = (k - 1) / 2, Lp = (L - kPoolK) / kPoolS + 1;
+  const float keep_scale = drop_p > 0.f ? 1.0f / (1.0f - drop_p) : 1.0f;
+  char* base = (char*)ws;
+  P* bpart = (P*)base;
+  P* coef = (P*)(base + w.bwd_partial);
+  P* slab = (P*)(base + w.bwd_partial + w.coef);
+  {   // dgamma / dbeta are defined in eval mode too (x-hat then uses the running statistics)
+    const size_t sm = (size_t)(256 / (Cout / VEC)) * 2 * Cout * sizeof(P);
+    if (dout_ncl)
+      bn_bwd_reduce_kernel<T, true><<<w.nblk_bwd, 256, sm, s>>>((const T*)dout, argmax, (const T*)y, (const P*)stats, bpart, B, L, Lp, Cout, keep_scale, w.rows_per_block);
+    else
+      bn_bwd_reduce_kernel<T, false><<<w.nblk_bwd, 256, sm, s>>>((const T*)dout, argmax, (const T*)y, (const P*)stats, bpart, B, L, Lp, Cout, keep_scale, w.rows_per_block);
+    EMB_CHECK_LAUNCH();
+    bn_bwd_finalize_kernel<P><<<Cout, 256, 0, s>>>(bpart, w.nblk_bwd, Cout, (double)R, (P*)dgamma, (P*)dbeta, coef);
+    EMB_CHECK_LAUNCH();
+  }
+  const long total = (long)R * (Cout / VEC);
+  const int grid = (int)((total + 255) / 256);
+  if (dout_ncl)
+    bn_bwd_apply_kernel<T, true><<<grid, 256, 0, s>>>((const T*)dout, argmax, (const T*)y, (const P*)stats, coef, (T*)dy, B, L, Lp, Cout, keep_scale, training);
+  else
+    bn_bwd_apply_kernel<T, false><<<grid, 256, 0, s>>>((const T*)dout, argmax, (const T*)y, (const P*)stats, coef, (T*)dy, B, L, Lp, Cout, keep_scale, training);
+  EMB_CHECK_LAUNCH();
+  // wgrad: split over the B*L reduction, slices reduced in order
+  {
+    const int tiles_n = cdiv(KK + 1, CW::BN), tiles = cdiv(Cout, CW::BM) * tiles_n;
+    const int vec_dy = (Cout % VEC == 0) && aligned16(dy), vec_x = (cin_pad % VEC == 0) && aligned16(x);
+    constexpr int lds = gemm_tile_lds<CW>();
+    static bool attr_set = false;
+    if (!attr_set && lds > 48 * 1024) {
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wgrad_kernel<CW>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+      attr_set = true;
+    }
+    conv_wgrad_kernel<CW><<<tiles * w.S, kThreads, lds, s>>>((const T*)dy, (const T*)x, slab, R, L, cin_pad, KK, Cout, pad, w.kper,
+                                                            tiles_n, tiles, vec_dy, vec_x);
+    EMB_CHECK_LAUNCH();
+    const long n = (long)Cout * Cin * k + Cout;
+    conv_wgrad_reduce_kernel<P><<<(int)((n + 255) / 256), 256, 0, s>>>(slab, w.S, Cout, Cin, cin_pad, k, (P*)dW, (P*)dbias);
+    EMB_CHECK_LAUNCH();
+  }
+  if (dx != nullptr) {   // dgrad: the same conv-view GEMM on dy with flipped taps
+    int rc;
+    if (cin_pad >= 64) rc = launch_conv_gemm<typename ConvCfg<T>::F64, false>(dy, wflip, nullptr, dx, nullptr, R, L, Cout, k * Cout, cin_pad, pad, s);
+    else rc = launch_conv_gemm<typename ConvCfg<T>::F32, false>(dy, wflip, nullptr, dx, nullptr, R, L, Cout, k * Cout, cin_pad, pad, s);
+    if (rc != EMB_OK) return rc;
+  }
+  return EMB_OK;
+}
+
+template <typename S> static int ncl_to_nlc_from(const void* x, void* out, int dd, int B, int C, int L, int Cpad, hipStream_t s) {
+  const long n = (long)B * L;
+  const int grid = (int)((n + 255) / 256);
+  switch (dd) {
+    case EMB_F32: ncl_to_nlc_kernel<S, float><<<grid, 256, 0, s>>>((const S*)x, (float*)out, B, C, L, Cpad); break;
+    case EMB_BF16: ncl_to_nlc_kernel<S, __bf16><<<grid, 256, 0, s>>>((const S*)x, (__bf16*)out, B, C, L, Cpad); break;
+    case EMB_F64: ncl_to_nlc_kernel<S, double><<<grid, 256, 0, s>>>((const S*)x, (double*)out, B, C, L, Cpad); break;
+    default: set_error("emb_ncl_to_nlc: unsupported dst dtype %d", dd); return EMB_ERR_DTYPE;
+  }
+  EMB_CHECK_LAUNCH();
+  return EMB_OK;
+}
+
+}  // namespace emb
+
+using namespace emb;
+
+extern "C" int64_t emb_convblock_workspace_bytes(int B, int L, int cin_pad, int Cout, int k, int dtype) {
+  if (B <= 0 || L <= 0 || cin_pad <= 0 || Cout <= 0 || k <= 0) return -1;
+  switch (dtype) {
+    case EMB_F32: return (int64_t)conv_workspace<float>(B, L, cin_pad, Cout, k).total;
+    case EMB_BF16: return (int64_t)conv_workspace<__bf16>(B, L, cin_pad, Cout, k).total;
+    case EMB_F64: return (int64_t)conv_workspace<double>(B, L, cin_pad, Cout, k).total;
+  }
+  return -1;
+}
+
+extern "C" int emb_ncl_to_nlc(const void* x, int src_dtype, void* out, int dst_dtype, int B, int C, int L, int Cpad,
+                              emb_stream_t stream) {
+  EMB_CHECK_ARG(x && out && B > 0 && C > 0 && L > 0 && Cpad >= C, "emb_ncl_to_nlc: bad argument");
+  hipStream_t s = (hipStream_t)stream;
+  switch (src_dtype) {
+    case EMB_F32: return ncl_to_nlc_from<float>(x, out, dst_dtype, B, C, L, Cpad, s);
+    case EMB_BF16: return ncl_to_nlc_from<__bf16>(x, out, dst_dtype, B, C, L, Cpad, s);
+    case EMB_F64: return ncl_to_nlc_from<double>(x, out, dst_dtype, B, C, L, Cpad, s);
+  }
+  set_error("emb_ncl_to_nlc: unsupported src dtype %d", src_dtype);
+  return EMB_ERR_DTYPE;
+}
+
+extern "C" int emb_conv_pack_weight(const void* W, void* wpack, void* wflip, int Cout, int Cin, int cin_pad, int k, int dtype,
+                                    emb_stream_t stream) {
+  EMB_CHECK_ARG(W && wpack && Cout > 0 && Cin > 0 && cin_pad >= Cin && k > 0, "emb_conv_pack_weight: bad argument");
+  hipStream_t s = (hipStream_t)stream;
+  const long n = (long)Cout * k * cin_pad * 2;
+  const int grid = (int)((n + 255) / 256);
+  switch (dtype) {
+    case EMB_F32: conv_pack_weight_kernel<float, float><<<grid, 256, 0, s>>>((const float*)W, (float*)wpack, (float*)wflip, Cout, Cin, cin_pad, k); break;
+    case EMB_BF16: conv_pack_weight_kernel<float, __bf16><<<grid, 256, 0, s>>>((const float*)W, (__bf16*)wpack, (__bf16*)wflip, Cout, Cin, cin_pad, k); break;
+    case EMB_F64: conv_pack_weight_kernel<double, double><<<grid, 256, 0, s>>>((const double*)W, (double*)wpack, (double*)wflip, Cout, Cin, cin_pad, k); break;
+    default: set_error("emb_conv_pack_weight: unsupported dtype %d", dtype); return EMB_ERR_DTYPE;
+  }
+  EMB_CHECK_LAUNCH();
+  return EMB_OK;
+}
+
+extern "C" int emb_convblock_fwd(const void* x, const void* wpack, const void* bias, const void* gamma, const void* beta,
+                                 void* running_mean, void* running_var, int training, double momentum, double eps,
+                                 float dropout_p, uint64_t seed, uint64_t step_val, const uint64_t* step_dev, int64_t row0,
+                                 int layer_id, void* y, void* stats, void* out, uint8_t* argmax, int out_ncl, void* workspace,
+                                 int64_t workspace_bytes, int B, int L, int cin_pad, int Cout, int k, int dtype,
+                                 emb_stream_t stream) {
+  EMB_CHECK_ARG(x && wpack && bias && gamma && beta && running_mean && running_var && y && stats && out && argmax && workspace,
+                "emb_convblock_fwd: null pointer");
+  EMB_CHECK_ARG(B > 0 && L > 0 && cin_pad > 0 && Cout > 0 && k > 0 && (k & 1), "emb_convblock_fwd: bad dims");
+  EMB_CHECK_ARG(dropout_p >= 0.f && dropout_p < 1.f, "emb_convblock_fwd: dropout_p must be in [0,1)");
+  hipStream_t s = (hipStream_t)stream;
+  switch (dtype) {
+    case EMB_F32: return convblock_fwd<float>(x, wpack, bias, gamma, beta, running_mean, running_var, training, momentum, eps, dropout_p, seed, step_val, step_dev, row0, layer_id, y, stats, out, argmax, out_ncl, workspace, workspace_bytes, B, L, cin_pad, Cout, k, s);
+    case EMB_BF16: return convblock_fwd<__bf16>(x, wpack, bias, gamma, beta, running_mean, running_var, training, momentum, eps, dropout_p, seed, step_val, step_dev, row0, layer_id, y, stats, out, argmax, out_ncl, workspace, workspace_bytes, B, L, cin_pad, Cout, k, s);
+    case EMB_F64: return convblock_fwd<double>(x, wpack, bias, gamma, beta, running_mean, running_var, training, momentum, eps, dropout_p, seed, step_val, step_dev, row0, layer_id, y, stats, out, argmax, out_ncl, workspace, workspace_bytes, B, L, cin_pad, Cout, k, s);
+  }
+  set_error("emb_convblock_fwd: unsupported dtype %d", dtype);
+  return EMB_ERR_DTYPE;
+}
+
+extern "C" int emb_convblock_bwd(const void* dout, int dout_ncl, const uint8_t* argmax, const void* y, const void* stats,
+                                 const void* x, const void* wflip, float dropout_p, int training, void* dx, void* dW, void* dbias,
+                                 void* dgamma, void* dbeta, void* dy, void* workspace, int64_t workspace_bytes, int B, int L,
+                                 int Cin, int cin_pad, int Cout, int k, int dtype, emb_stream_t stream) {
+  EMB_CHECK_ARG(dout && argmax && y && stats && x && dW && dbias && dgamma && dbeta && dy && workspace,
+                "emb_convblock_bwd: null pointer");
+  EMB_CHECK_ARG(dx == nullptr || wflip != nullptr, "emb_convblock_bwd: wflip is required when dx is requested");
+  EMB_CHECK_ARG(B > 0 && L > 0 && Cin > 0 && cin_pad >= Cin && Cout > 0 && k > 0 && (k & 1), "emb_convblock_bwd: bad dims");
+  hipStream_t s = (hipStream_t)stream;
+  switch (dtype) {
+    case EMB_F32: return convblock_bwd<float>(dout, dout_ncl, argmax, y, stats, x, wflip, dropout_p, training, dx, dW, dbias, dgamma, dbeta, dy, workspace, workspace_bytes, B, L, Cin, cin_pad, Cout, k, s);
+    case EMB_BF16: return convblock_bwd<__bf16>(dout, dout_ncl, argmax, y, stats, x, wflip, dropout_p, training, dx, dW, dbias, dgamma, dbeta, dy, workspace, workspace_bytes, B, L, Cin, cin_pad, Cout, k, s);
+    case EMB_F64: return convblock_bwd<double>(dout, dout_ncl, argmax, y, stats, x, wflip, dropout_p, training, dx, dW, dbias, dgamma, dbeta, dy, workspace, workspace_bytes, B, L, Cin, cin_pad, Cout, k, s);
+  }
+  set_error("emb_convblock_bwd: unsupported dtype %d", dtype);
+  return EMB_ERR_DTYPE;
+}

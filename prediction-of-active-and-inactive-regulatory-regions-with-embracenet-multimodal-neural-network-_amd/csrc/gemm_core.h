@@ -101,6 +101,11 @@ template <typename T, bool KMAJOR, int ROWS, int BK, typename Xf> struct Stager 
   bool vec_ok;  // 16-byte loads legal (alignment of base and ld)
   Xf xf;
   int ones_row;  // >= 0: operand row that reads as 1.0 for every k < K (bias-gradient column), else -1
+  // Convolution view (cv_L > 0): the operand is the im2col matrix of a channels-last activation
+  // x[B, L, cin]: rows R = b*L + t, columns KK = tap*cin + ci, element = x[b, t - pad + tap, ci] or 0 outside
+  // [0, L).  Rows overlap in memory, so the address is simply (R - pad)*cin + KK; only validity depends on
+  // (t, tap).  Row-major use: (r, k) = (R, KK); K-major use: (r, k) = (KK, R).  Requires cin % VEC == 0.
+  int cv_L, cv_cin, cv_pad;
   V regs[NV];
 
   __device__ void load(int k0) {
@@ -115,10 +120,20 @@ template <typename T, bool KMAJOR, int ROWS, int BK, typename Xf> struct Stager 
         const int outer = v / INNER, inner = (v % INNER) * VEC;
         const int r = row0 + (KMAJOR ? inner : outer);
         const int k = k0 + (KMAJOR ? outer : inner);
-        const int rlim = KMAJOR ? nrows - r : (r < nrows ? VEC : 0);   // valid elements along the vector...
-        const int klim = KMAJOR ? (k < K ? VEC : 0) : K - k;           // ...and across it
-        const int nvalid = KMAJOR ? (klim > 0 ? rlim : 0) : (rlim > 0 ? klim : 0);
-        const long off = KMAJOR ? (long)k * ld + r : (long)r * ld + k;
+        int nvalid;
+        long off;
+        if (cv_L > 0) {
+          const int R = KMAJOR ? k : r, KK = KMAJOR ? r : k;
+          const int nR = KMAJOR ? K : nrows, nKK = KMAJOR ? nrows : K;
+          const int tt = R % cv_L - cv_pad + KK / cv_cin;     // time index the tap reads
+          nvalid = (R < nR && tt >= 0 && tt < cv_L) ? nKK - KK : 0;
+          off = ((long)R - cv_pad) * cv_cin + KK;
+        } else {
+          const int rlim = KMAJOR ? nrows - r : (r < nrows ? VEC : 0);   // valid elements along the vector...
+          const int klim = KMAJOR ? (k < K ? VEC : 0) : K - k;           // ...and across it
+          nvalid = KMAJOR ? (klim > 0 ? rlim : 0) : (rlim > 0 ? klim : 0);
+          off = KMAJOR ? (long)k * ld + r : (long)r * ld + k;
+        }
         if (nvalid >= VEC && vec_ok) {
           val = *reinterpret_cast<const V*>(g + off);
           if (Xf::kUsesCode) {
@@ -220,17 +235,17 @@ template <typename T_, int BM_, int BN_, int BK_, int WM_, int WN_, int WK_, boo
 // may be reused immediately.
 template <class Cfg, class StA, class StB>
 __device__ __forceinline__ void gemm_mainloop(StA& sa, StB& sb, int K, char* arena,
-                                              typename Cfg::M::AccV (&acc)[Cfg::MI][Cfg::NI]) {
+                                              typename Cfg::M::AccV (&acc)[Cfg::MI][Cfg::NI], int k_begin = 0) {
   using T = typename Cfg::T;
   using M = typename Cfg::M;
   T* As[2] = {reinterpret_cast<T*>(arena), reinterpret_cast<T*>(arena) + Cfg::A_ELEMS};
   T* Bs[2] = {reinterpret_cast<T*>(arena) + 2 * Cfg::A_ELEMS, reinterpret_cast<T*>(arena) + 2 * Cfg::A_ELEMS + Cfg::B_ELEMS};
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int wk = wave % Cfg::WK, wn = (wave / Cfg::WK) % Cfg::WN, wm = wave / (Cfg::WK * Cfg::WN);
-  const int nchunks = (K + Cfg::BK - 1) / Cfg::BK;
+  const int nchunks = (K - k_begin + Cfg::BK - 1) / Cfg::BK;   // K is the exclusive end of the k range
 
-  sa.load(0);
-  sb.load(0);
+  sa.load(k_begin);
+  sb.load(k_begin);
   sa.store(As[0]);
   sb.store(Bs[0]);
   __syncthreads();
@@ -238,15 +253,15 @@ __device__ __forceinline__ void gemm_mainloop(StA& sa, StB& sb, int K, char* are
     const int cur = ch & 1;
     const bool more = ch + 1 < nchunks;
     if (more) {
-      sa.load((ch + 1) * Cfg::BK);   // in flight while this chunk is multiplied
-      sb.load((ch + 1) * Cfg::BK);
+      sa.load(k_begin + (ch + 1) * Cfg::BK);   // in flight while this chunk is multiplied
+      sb.load(k_begin + (ch + 1) * Cfg::BK);
     }
     const T* At = As[cur];
     const T* Bt = Bs[cur];
 #pragma unroll
     for (int ks = 0; ks < Cfg::KW / M::KSTEP; ++ks) {
       const int kb = wk * Cfg::KW + ks * M::KSTEP;
-      if (ch * Cfg::BK + kb < K) {   // wave-uniform: skip zero padding past K
+      if (k_begin + ch * Cfg::BK + kb < K) {   // wave-uniform: skip zero padding past K
         typename M::Frag af[Cfg::MI], bf[Cfg::NI];
 #pragma unroll
         for (int mi = 0; mi < Cfg::MI; ++mi)

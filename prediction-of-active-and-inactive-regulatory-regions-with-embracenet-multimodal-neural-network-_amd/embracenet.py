@@ -184,15 +184,16 @@ class EmbraceNetMultimodal(nn.Module, _RngMixin):
         x_FFNN, x_CNN = x
         dev = x_FFNN.device
         T = self.compute_dtype or self.embracenet.docking_0.weight.dtype
-        if T == torch.bfloat16:
-            with torch.autocast("cuda", dtype=torch.bfloat16):
-                h0, h1 = self.FFNN(x_FFNN), self.CNN(x_CNN)
-        else:
-            h0, h1 = self.FFNN(x_FFNN), self.CNN(x_CNN)
-        B = h0.shape[0]
-
         self.embracenet.rng_mode, self.embracenet.generator = self.rng_mode, self.generator
         self.embracenet.rng_seed, self.embracenet.rng_row0 = self.rng_seed, self.rng_row0
+        rng = self.embracenet._rng_state(dev) if x_FFNN.is_cuda else None
+        self.FFNN.compute_dtype = self.CNN.compute_dtype = self.compute_dtype
+        if T == torch.bfloat16 and not (self.FFNN.use_hip and self.CNN.use_hip):
+            with torch.autocast("cuda", dtype=torch.bfloat16):          # stock-operator A/B path only
+                h0, h1 = self.FFNN(x_FFNN, rng=rng), self.CNN(x_CNN, rng=rng)
+        else:
+            h0, h1 = self.FFNN(x_FFNN, rng=rng), self.CNN(x_CNN, rng=rng)
+        B = h0.shape[0]
         device_dropout = False
         if is_training and embracenet_dropout:                              # :178-182
             if self.rng_mode == "host":
@@ -210,7 +211,6 @@ class EmbraceNetMultimodal(nn.Module, _RngMixin):
         p = self._sel_dev
         E = self.embracenet([h0, h1], availabilities=availabilities, selection_probabilities=p,
                             _device_dropout=device_dropout, _advance=False)
-        rng = self.embracenet._rng_state(dev)
         out = self._post_forward(E, rng, T)
         self.embracenet._advance_step()
         return out

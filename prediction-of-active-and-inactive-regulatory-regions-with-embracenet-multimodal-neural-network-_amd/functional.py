@@ -195,3 +195,115 @@ def cast(src, dtype, out=None):
     out = out if out is not None else torch.empty(src.shape, dtype=dtype, device=src.device)
     check(_lib.lib().emb_cast(ptr(src), DTYPE_CODE[src.dtype], ptr(out), DTYPE_CODE[dtype], src.numel(), stream()), "emb_cast")
     return out
+
+
+# ------------------------------------------------------------------------------------------------------
+# sequence pre-network (CNN_pre.py:24-76): the whole Conv1d->BN->ReLU->MaxPool(->Dropout) stack as ONE
+# autograd node; activations are channels-last between blocks, the last block emits the reference's
+# [B, C*Lp] flatten order.
+_WORKSPACE = {}
+
+
+def _workspace(device, nbytes):
+    buf = _WORKSPACE.get(device)
+    if buf is None or buf.numel() < nbytes:
+        buf = torch.empty(int(nbytes), dtype=torch.uint8, device=device)
+        _WORKSPACE[device] = buf
+    return buf
+
+
+def _vec(dtype):
+    return 16 // torch.empty(0, dtype=dtype).element_size()
+
+
+def pool_out_len(L):
+    return (L - 10) // 2 + 1
+
+
+class _ConvStackFn(torch.autograd.Function):
+    """args: x [B,C,L], training, rng, T, meta (tuple of per-layer dicts: k, drop_p, momentum, eps, layer_id), then per
+    layer: conv.weight, conv.bias, bn.weight, bn.bias, bn.running_mean, bn.running_var."""
+
+    @staticmethod
+    def forward(ctx, x, training, rng, T, meta, *tensors):
+        _lib.require_cuda(x)
+        L_ = _lib.lib()
+        P = PARAM_DTYPE[T]
+        dev, code = x.device, DTYPE_CODE[T]
+        B, C0, L = x.shape
+        x = x if x.is_contiguous() else x.contiguous()
+        vec = _vec(T)
+        cin_pad = -(-C0 // vec) * vec
+        cur = torch.empty(B, L, cin_pad, dtype=T, device=dev)
+        check(L_.emb_ncl_to_nlc(ptr(x), DTYPE_CODE[x.dtype], ptr(cur), code, B, C0, L, cin_pad, stream()), "emb_ncl_to_nlc")
+        saved, shapes = [], []
+        n_layers = len(meta)
+        for i, m in enumerate(meta):
+            w, b, g, beta, rmean, rvar = tensors[6 * i:6 * i + 6]
+            for t in (w, b, g, beta, rmean, rvar):
+                if t.dtype != P:
+                    raise TypeError(f"conv stack parameters must be {P} for compute dtype {T}")
+            Cout, Cin, k = w.shape
+            wpack = torch.empty(Cout, k * cin_pad, dtype=T, device=dev)
+            wflip = torch.empty(cin_pad, k * Cout, dtype=T, device=dev) if i > 0 else None
+            check(L_.emb_conv_pack_weight(ptr(w.detach().contiguous()), ptr(wpack), ptr(wflip), Cout, Cin, cin_pad, k, code,
+                                          stream()), "emb_conv_pack_weight")
+            Lp = pool_out_len(L)
+            last = i == n_layers - 1
+            y = torch.empty(B, L, Cout, dtype=T, device=dev)
+            stats = torch.empty(4, Cout, dtype=P, device=dev)
+            out = torch.empty((B, Cout, Lp) if last else (B, Lp, Cout), dtype=T, device=dev)
+            argmax = torch.empty(B, Lp, Cout, dtype=torch.uint8, device=dev)
+            nbytes = L_.emb_convblock_workspace_bytes(B, L, cin_pad, Cout, k, code)
+            ws = _workspace(dev, nbytes)
+            check(L_.emb_convblock_fwd(ptr(cur), ptr(wpack), ptr(b.detach()), ptr(g.detach()), ptr(beta.detach()), ptr(rmean),
+                                       ptr(rvar), int(training), float(m["momentum"]), float(m["eps"]), float(m["drop_p"]),
+                                       rng.seed, rng.step_val, ptr(rng.step_dev), rng.row0, int(m["layer_id"]), ptr(y),
+                                       ptr(stats), ptr(out), ptr(argmax), int(last), ptr(ws), ws.numel(), B, L, cin_pad, Cout,
+                                       k, code, stream()), "emb_convblock_fwd")
+            saved += [cur, y, stats, argmax, wflip if wflip is not None else stats]
+            shapes.append((L, Cin, cin_pad, Cout, k, float(m["drop_p"])))
+            cur, L, cin_pad = out, Lp, Cout
+        ctx.save_for_backward(*saved)
+        ctx.cfg = (T, int(training), B, shapes)
+        return cur.reshape(B, -1)
+
+    @staticmethod
+    def backward(ctx, dout):
+        T, training, B, shapes = ctx.cfg
+        P = PARAM_DTYPE[T]
+        L_ = _lib.lib()
+        code = DTYPE_CODE[T]
+        saved = ctx.saved_tensors
+        dev = dout.device
+        g = _as(dout, T)
+        grads = [None] * (6 * len(shapes))
+        for i in reversed(range(len(shapes))):
+            xin, y, stats, argmax, wflip = saved[5 * i:5 * i + 5]
+            L, Cin, cin_pad, Cout, k, drop_p = shapes[i]
+            last = i == len(shapes) - 1
+            dy = torch.empty(B, L, Cout, dtype=T, device=dev)
+            dx = torch.empty(B, L, cin_pad, dtype=T, device=dev) if i > 0 else None
+            dW = torch.empty(Cout, Cin, k, dtype=P, device=dev)
+            db, dgam, dbeta = (torch.empty(Cout, dtype=P, device=dev) for _ in range(3))
+            nbytes = L_.emb_convblock_workspace_bytes(B, L, cin_pad, Cout, k, code)
+            ws = _workspace(dev, nbytes)
+            check(L_.emb_convblock_bwd(ptr(g), int(last), ptr(argmax), ptr(y), ptr(stats), ptr(xin),
+                                       ptr(wflip) if i > 0 else None, drop_p, training, ptr(dx), ptr(dW), ptr(db), ptr(dgam),
+                                       ptr(dbeta), ptr(dy), ptr(ws), ws.numel(), B, L, Cin, cin_pad, Cout, k, code, stream()),
+                  "emb_convblock_bwd")
+            grads[6 * i:6 * i + 4] = [dW, db, dgam, dbeta]
+            g = dx
+        return (None, None, None, None, None, *grads)
+
+
+def conv_stack(x, layers, training, rng=None, compute_dtype=None):
+    """layers: list of dicts with conv (nn.Conv1d), bn (nn.BatchNorm1d), drop_p, layer_id."""
+    T = compute_dtype or layers[0]["conv"].weight.dtype
+    meta, tensors = [], []
+    for ly in layers:
+        conv, bn = ly["conv"], ly["bn"]
+        meta.append(dict(k=conv.kernel_size[0], drop_p=ly["drop_p"] if training else 0.0,
+                         momentum=0.1 if bn.momentum is None else bn.momentum, eps=bn.eps, layer_id=ly["layer_id"]))
+        tensors += [conv.weight, conv.bias, bn.weight, bn.bias, bn.running_mean, bn.running_var]
+    return _ConvStackFn.apply(x, bool(training), rng or RngState(), T, tuple(meta), *tensors)

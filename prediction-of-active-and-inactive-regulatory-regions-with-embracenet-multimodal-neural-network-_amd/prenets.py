@@ -6,13 +6,19 @@ same order, same ``output_size`` attribute and the same state-dict keys ``model.
   FFNN_pre  <- BIOINF_tesi/models/FFNN_pre.py:10-49   epigenomic features  [B,F]     -> [B,d0]
   CNN_pre   <- BIOINF_tesi/models/CNN_pre.py:10-76    one-hot DNA window   [B,4,256] -> [B,d1]
 
-SURVEY 8(f1): these are "next" rows.  In this round they run on stock PyTorch-ROCm operators
-(hipBLASLt / MIOpen); the hand-written HIP path starts at the docking layers.
+The ``nn.Sequential`` members only HOLD the parameters (names, shapes, init, ``weight_reset``); on a ROCm
+device ``forward`` runs the hand-written kernels: FFNN_pre = fused Linear+ReLU+Dropout GEMMs
+(csrc/linear.hip), CNN_pre = conv-as-GEMM on a channels-last im2col view + fused BN/ReLU/MaxPool
+(csrc/convblock.hip).  ``use_hip = False`` falls back to the stock torch operators (kept for A/B timing).
 """
 import torch.nn as nn
 
+from . import functional as F_
+
 _FFNN_UNITS = ([32, 64, 128, 256], [16, 32, 64, 128], [4, 16, 32, 64], [4, 16, 32])
 _CNN_CHANNELS = ([16, 32, 64], [32, 64, 96], [64, 96, 128, 256], [128, 256, 512])
+# RNG layer ids (dropout streams, include/embrace_hip.h): post stack 0-3, CNN blocks 4-7, FFNN layers 8-11
+_CNN_LAYER_ID0, _FFNN_LAYER_ID0 = 4, 8
 
 
 def conv_output_length(length, kernel, padding, stride):
@@ -33,9 +39,19 @@ class FFNN_pre(nn.Module):
             width = out
         self.output_size = width
         self.model = nn.Sequential(*stack)
+        self.compute_dtype = None
+        self.use_hip = True
 
-    def forward(self, x):
-        return self.model(x)
+    def forward(self, x, rng=None):
+        if not (self.use_hip and x.is_cuda):
+            return self.model(x)
+        T = self.compute_dtype or self.model[0].weight.dtype
+        mods = list(self.model)
+        for i in range(0, len(mods), 3):
+            p = float(mods[i + 2].p) if self.training else 0.0
+            x = F_.linear(x, mods[i].weight, mods[i].bias, relu=True, dropout_p=p, layer_id=_FFNN_LAYER_ID0 + i // 3,
+                          rng=rng, compute_dtype=T)
+        return x
 
 
 class CNN_pre(nn.Module):
@@ -56,7 +72,19 @@ class CNN_pre(nn.Module):
             length = conv_output_length(conv_output_length(length, k, pad, 1), 10, 0, 2)
         self.output_size = channels * length
         self.CNN_model = nn.Sequential(*stack)
+        self.compute_dtype = None
+        self.use_hip = True
 
-    def forward(self, x):
-        y = self.CNN_model(x)
-        return y.reshape(y.size(0), -1)
+    def forward(self, x, rng=None):
+        if not (self.use_hip and x.is_cuda):
+            y = self.CNN_model(x)
+            return y.reshape(y.size(0), -1)
+        mods = list(self.CNN_model)
+        layers = []
+        for i in range(0, len(mods), 5):
+            conv, bn, drop = mods[i], mods[i + 1], mods[i + 4]
+            layers.append(dict(conv=conv, bn=bn, drop_p=float(drop.p), layer_id=_CNN_LAYER_ID0 + i // 5))
+            if self.training and bn.track_running_stats and bn.num_batches_tracked is not None:
+                bn.num_batches_tracked.add_(1)
+        T = self.compute_dtype or mods[0].weight.dtype
+        return F_.conv_stack(x, layers, self.training, rng=rng, compute_dtype=T)

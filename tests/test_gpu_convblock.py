@@ -1,0 +1,139 @@
+"""GPU: the hand-written sequence pre-network (conv-as-GEMM + BN/ReLU/MaxPool, csrc/convblock.hip) against the
+same stack of stock PyTorch operators evaluated in fp64 on the CPU (CNN_pre.py:37-50 semantics).
+Tolerances: fp64 1e-9; fp32 2e-4 relative to the tensor's scale (BatchNorm divides by the batch std, so fp32
+rounding of the conv output is amplified); bf16 4e-2 (operands rounded to bf16 first so only kernel-side
+rounding is measured).  argmax / dropout decisions are integer work and are covered through their effect on the
+gradients."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as TF
+
+from oracle import datagen as dg
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+TD = {"f64": torch.float64, "f32": torch.float32, "bf16": torch.bfloat16}
+TOL = {"f64": 1e-9, "f32": 2e-4, "bf16": 4e-2}
+
+
+class Blk:
+    def __init__(self, name, cin, cout, k, dtype_p):
+        self.conv = torch.nn.Conv1d(cin, cout, k, padding=(k - 1) // 2).to(dtype_p)
+        self.bn = torch.nn.BatchNorm1d(cout).to(dtype_p)
+        with torch.no_grad():
+            self.conv.weight.copy_(torch.from_numpy(dg.weight(name + "/w", (cout, cin, k), cin * k)))
+            self.conv.bias.copy_(torch.from_numpy(dg.weight(name + "/b", (cout,), cin * k)))
+            self.bn.weight.copy_(torch.from_numpy(dg.uniform(name + "/g", (cout,), 0.5, 1.5)))
+            self.bn.bias.copy_(torch.from_numpy(dg.uniform(name + "/beta", (cout,), -0.3, 0.3)))
+
+    def params(self):
+        return [self.conv.weight, self.conv.bias, self.bn.weight, self.bn.bias]
+
+
+def reference(x, blocks, training):
+    h = x
+    for b in blocks:
+        h = TF.conv1d(h, b.conv.weight, b.conv.bias, padding=b.conv.padding[0])
+        h = TF.batch_norm(h, b.bn.running_mean, b.bn.running_var, b.bn.weight, b.bn.bias, training, 0.1, 1e-5)
+        h = TF.max_pool1d(TF.relu(h), 10, 2)
+    return h.reshape(h.shape[0], -1)
+
+
+CASES = [
+    ("a549", 64, [(4, 64, 15), (64, 32, 15)]),            # trial-0 stack of the Optuna DB (d1 = 1856)
+    ("one", 37, [(4, 16, 5)]),
+    ("deep", 16, [(4, 32, 5), (32, 32, 5), (32, 128, 11), (128, 128, 15)]),   # BASELINE cfg4 stack, L: 256..8
+    ("odd", 9, [(4, 96, 11), (96, 64, 5)]),
+]
+
+
+@pytest.mark.parametrize("dt", ["f64", "f32", "bf16"])
+@pytest.mark.parametrize("training", [True, False])
+@pytest.mark.parametrize("case", CASES, ids=[c[0] for c in CASES])
+def test_conv_stack_matches_torch_reference(ea, case, training, dt):
+    name, B, spec = case
+    T = TD[dt]
+    P = torch.float64 if dt == "f64" else torch.float32
+    x = dg.onehot_sequence(f"cb/{name}/x", B)
+    rnd = lambda t: t.to(T).double() if dt == "bf16" else t.double()
+    ref_blocks = [Blk(f"cb/{name}/{i}", ci, co, k, torch.float64) for i, (ci, co, k) in enumerate(spec)]
+    gpu_blocks = [Blk(f"cb/{name}/{i}", ci, co, k, P) for i, (ci, co, k) in enumerate(spec)]
+    if dt == "bf16":      # the kernel sees bf16-rounded conv weights: give the reference the same values
+        with torch.no_grad():
+            for b in ref_blocks:
+                b.conv.weight.copy_(rnd(b.conv.weight))
+    if not training:
+        with torch.no_grad():
+            for rb, gb in zip(ref_blocks, gpu_blocks):
+                for bn in (rb.bn, gb.bn):
+                    bn.running_mean.copy_(torch.from_numpy(dg.uniform("cb/rm", (bn.num_features,), -0.2, 0.2)))
+                    bn.running_var.copy_(torch.from_numpy(dg.uniform("cb/rv", (bn.num_features,), 0.5, 2.0)))
+    xr = torch.from_numpy(x)
+    out_ref = reference(xr, ref_blocks, training)
+    dout = torch.from_numpy(dg.uniform(f"cb/{name}/dout", tuple(out_ref.shape), -1, 1))
+    if dt == "bf16":
+        dout = rnd(dout)
+    out_ref.backward(dout)
+
+    for b in gpu_blocks:
+        b.conv.to(DEV); b.bn.to(DEV)
+    layers = [dict(conv=b.conv, bn=b.bn, drop_p=0.0, layer_id=4 + i) for i, b in enumerate(gpu_blocks)]
+    out = ea.functional.conv_stack(xr.to(DEV, P), layers, training, compute_dtype=T)
+    assert out.shape == out_ref.shape
+    scale = max(1.0, out_ref.abs().max().item())
+    err = (out.double().cpu() - out_ref.detach()).abs().max().item() / scale
+    assert err < TOL[dt], ("forward", err)
+    out.backward(dout.to(DEV, T))
+    for rb, gb in zip(ref_blocks, gpu_blocks):
+        for pr, pg, nm in zip(rb.params(), gb.params(), ("w", "b", "gamma", "beta")):
+            s = max(1e-3, pr.grad.abs().max().item())
+            e = (pg.grad.double().cpu() - pr.grad).abs().max().item() / s
+            if nm == "b" and training:
+                continue      # mathematically zero behind BatchNorm: both sides hold rounding noise
+            assert e < TOL[dt] * 20, (nm, e)
+        if training:
+            assert (gb.bn.running_mean.double().cpu() - rb.bn.running_mean).abs().max() < max(TOL[dt], 1e-6) * 3
+            assert (gb.bn.running_var.double().cpu() - rb.bn.running_var).abs().max() < max(TOL[dt], 1e-6) * 3
+
+
+def test_conv_stack_is_deterministic_and_dropout_scales(ea):
+    F = ea.functional
+    B, spec = 32, [(4, 32, 5), (32, 32, 11)]
+    x = torch.from_numpy(dg.onehot_sequence("cbd/x", B)).to(DEV, torch.float32)
+    blocks = [Blk(f"cbd/{i}", ci, co, k, torch.float32) for i, (ci, co, k) in enumerate(spec)]
+    for b in blocks:
+        b.conv.to(DEV); b.bn.to(DEV)
+    mk = lambda p: [dict(conv=b.conv, bn=b.bn, drop_p=p, layer_id=4 + i) for i, b in enumerate(blocks)]
+    a = F.conv_stack(x, mk(0.0), True, rng=F.RngState(5, 1))
+    b_ = F.conv_stack(x, mk(0.0), True, rng=F.RngState(5, 1))
+    assert torch.equal(a, b_)
+    d1 = F.conv_stack(x, mk(0.4), True, rng=F.RngState(5, 2))
+    d2 = F.conv_stack(x, mk(0.4), True, rng=F.RngState(5, 2))
+    d3 = F.conv_stack(x, mk(0.4), True, rng=F.RngState(5, 3))
+    assert torch.equal(d1, d2) and not torch.equal(d1, d3)
+    e = F.conv_stack(x, mk(0.4), False)       # eval: dropout off
+    assert torch.isfinite(e).all()
+
+
+def test_full_model_hip_prenets_match_stock_operators(ea):
+    """same model, same batch: HIP pre-nets vs the stock torch operators (use_hip=False) agree in fp64."""
+    from oracle.configs import CONFIGS, FixedTrial
+    hp, F_in = CONFIGS["cfg1"]
+    m = ea.EmbraceNetMultimodal(FixedTrial(hp), "A549", "active_E_vs_inactive_E", DEV, F_in).double().to(DEV).set_rng("host")
+    x1 = torch.from_numpy(dg.features("fm/x1", 48, F_in)).to(DEV)
+    x2 = torch.from_numpy(dg.onehot_sequence("fm/x2", 48)).to(DEV)
+    m.train()
+    outs = []
+    for hip in (True, False):
+        m.FFNN.use_hip = m.CNN.use_hip = hip
+        for bn in [mod for mod in m.modules() if isinstance(mod, torch.nn.BatchNorm1d)]:
+            bn.reset_running_stats()
+        torch.manual_seed(11)
+        out = m([x1, x2], is_training=True)
+        m.zero_grad()
+        out.square().sum().backward()
+        outs.append((out.detach().clone(), m.CNN.CNN_model[0].weight.grad.clone(), m.FFNN.model[0].weight.grad.clone(),
+                     m.CNN.CNN_model[1].running_var.clone()))
+    for a, b in zip(*outs):
+        assert (a - b).abs().max().item() < 1e-9 * max(1.0, b.abs().max().item())

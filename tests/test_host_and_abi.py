@@ -18,7 +18,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 def test_library_exports_every_declared_symbol(ea):
     header = open(os.path.join(ROOT, "include", "embrace_hip.h")).read()
-    declared = set(re.findall(r"^(?:int|const char\*)\s+(emb_\w+)\s*\(", header, flags=re.M))
+    declared = set(re.findall(r"^(?:int|int64_t|const char\*)\s+(emb_\w+)\s*\(", header, flags=re.M))
     assert len(declared) >= 14
     assert declared == set(ea._lib.SIGNATURES), "binding table and header disagree"
     if not os.path.exists(ea._lib.LIB_PATH):
