@@ -95,9 +95,12 @@ int emb_linear_fwd(const void* X, const void* W, const void* b, void* Y, uint8_t
                    int64_t row0, int B, int K, int N, int dtype, emb_stream_t stream);
 
 /* backward of emb_linear_fwd: dZ = dY * mask-derived factor; dX = dZ W; dW = dZ^T X; db = sum_b dZ.
- *   dX [B,K] T (nullable), dW [N,K] P, db [N] P */
+ *   dX [B,K] T (nullable), dW [N,K] P, db [N] P
+ *   workspace (nullable): transient scratch; when given and the layer is small (few output tiles, long batch)
+ *   the weight gradient is split over the batch and reduced in a fixed order. */
 int emb_linear_bwd(const void* dY, const uint8_t* mask, const void* X, const void* W, void* dX, void* dW,
-                   void* db, int relu, float dropout_p, int B, int K, int N, int dtype, emb_stream_t stream);
+                   void* db, int relu, float dropout_p, void* workspace, int64_t workspace_bytes, int B, int K,
+                   int N, int dtype, emb_stream_t stream);
 
 /* utils/utils.py:121-140 (per-batch class weights) + nn.CrossEntropyLoss(weight) on output.float()
  * (utils/training_models_multimodal.py:140-141,151-154) + argmax confusion counts for the per-batch
@@ -127,6 +130,22 @@ int emb_nadam_step(void* param, const void* grad, void* exp_avg, void* exp_avg_s
                    void* bf16_shadow, int64_t n, double lr, double beta1, double beta2, double eps,
                    double weight_decay, double schedule_decay, uint64_t step_val, const uint64_t* step_dev,
                    int dtype, emb_stream_t stream);
+
+/* Multi-tensor forms: ONE launch updates `ntensors` parameter tensors (<= 40 per launch, chunked inside).
+ * The pointer / size arrays are HOST arrays read at call time (they travel in the kernel argument, so a
+ * captured call replays with the captured addresses); the tensors they point to are device memory.
+ * Nadam's m_schedule is one shared device double[2] (all parameters share the momentum schedule). */
+int emb_adam_step_multi(void* const* params, const void* const* grads, void* const* exp_avg, void* const* exp_avg_sq,
+                        void* const* bf16_shadows, const int64_t* sizes, int ntensors, double lr, double beta1,
+                        double beta2, double eps, double weight_decay, uint64_t step_val, const uint64_t* step_dev,
+                        int dtype, emb_stream_t stream);
+int emb_rmsprop_step_multi(void* const* params, const void* const* grads, void* const* square_avg,
+                           void* const* bf16_shadows, const int64_t* sizes, int ntensors, double lr, double alpha,
+                           double eps, double weight_decay, int dtype, emb_stream_t stream);
+int emb_nadam_step_multi(void* const* params, const void* const* grads, void* const* exp_avg, void* const* exp_avg_sq,
+                         double* m_schedule, void* const* bf16_shadows, const int64_t* sizes, int ntensors, double lr,
+                         double beta1, double beta2, double eps, double weight_decay, double schedule_decay,
+                         uint64_t step_val, const uint64_t* step_dev, int dtype, emb_stream_t stream);
 
 /* ---- sequence pre-network; activations channels-last x[B][L][C] --------------------------
  * One block of CNN_pre.py:37-50: Conv1d(k odd, stride 1, same padding) -> BatchNorm1d -> ReLU ->

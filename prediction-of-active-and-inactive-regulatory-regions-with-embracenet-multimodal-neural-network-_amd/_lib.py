@@ -32,12 +32,15 @@ SIGNATURES = {
     "emb_embrace_fwd": [_vp] * 8 + [_u64, _u64, _vp, _i64, _vp, _vp, _i, _i, _i, _i, _i, _vp],
     "emb_embrace_bwd": [_vp] * 12 + [_i, _i, _i, _i, _i, _vp],
     "emb_linear_fwd": [_vp] * 5 + [_i, _f, _i, _u64, _u64, _vp, _i64, _i, _i, _i, _i, _vp],
-    "emb_linear_bwd": [_vp] * 7 + [_i, _f, _i, _i, _i, _i, _vp],
+    "emb_linear_bwd": [_vp] * 7 + [_i, _f, _vp, _i64, _i, _i, _i, _i, _vp],
     "emb_weighted_ce": [_vp, _vp, _vp, _i, _vp, _vp, _vp, _i, _i, _vp],
     "emb_count_labels": [_vp, _vp, _i, _vp],
     "emb_adam_step": [_vp] * 5 + [_i64, _d, _d, _d, _d, _d, _u64, _vp, _i, _vp],
     "emb_rmsprop_step": [_vp] * 4 + [_i64, _d, _d, _d, _d, _i, _vp],
     "emb_nadam_step": [_vp] * 6 + [_i64, _d, _d, _d, _d, _d, _d, _u64, _vp, _i, _vp],
+    "emb_adam_step_multi": [_vp] * 6 + [_i, _d, _d, _d, _d, _d, _u64, _vp, _i, _vp],
+    "emb_rmsprop_step_multi": [_vp] * 5 + [_i, _d, _d, _d, _d, _i, _vp],
+    "emb_nadam_step_multi": [_vp] * 7 + [_i, _d, _d, _d, _d, _d, _d, _u64, _vp, _i, _vp],
     "emb_convblock_workspace_bytes": [_i, _i, _i, _i, _i, _i],
     "emb_ncl_to_nlc": [_vp, _i, _vp, _i, _i, _i, _i, _i, _vp],
     "emb_conv_pack_weight": [_vp, _vp, _vp, _i, _i, _i, _i, _i, _vp],

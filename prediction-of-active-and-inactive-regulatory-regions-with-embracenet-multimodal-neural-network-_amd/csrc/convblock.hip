@@ -436,21 +436,18 @@ __global__ __launch_bounds__(kThreads) void conv_wgrad_kernel(const typename Cfg
 template <typename P>
 __global__ void conv_wgrad_reduce_kernel(const P* __restrict__ slab, int S, int Cout, int Cin, int cin_pad, int k,
                                          P* __restrict__ dW, P* __restrict__ dbias) {
+  // one thread per SLAB element: the S reads of a wavefront are contiguous; the (small) result is scattered
   const int KK = k * cin_pad;
-  const long n_w = (long)Cout * Cin * k;
-  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n_w + Cout) return;
-  long src;
-  if (i < n_w) {
-    const int j = (int)(i % k), ci = (int)((i / k) % Cin), o = (int)(i / ((long)k * Cin));
-    src = (long)o * (KK + 1) + (long)j * cin_pad + ci;
-  } else {
-    src = (long)(i - n_w) * (KK + 1) + KK;
-  }
+  const long per = (long)Cout * (KK + 1);
+  const long q = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (q >= per) return;
+  const int o = (int)(q / (KK + 1)), col = (int)(q % (KK + 1));
+  const int j = col / cin_pad, ci = col % cin_pad;
+  if (col < KK && ci >= Cin) return;   // zero-padded input channel
   P a = 0;
-  for (int s = 0; s < S; ++s) a += slab[(long)s * Cout * (KK + 1) + src];
-  if (i < n_w) dW[i] = a;
-  else dbias[i - n_w] = a;
+  for (int s = 0; s < S; ++s) a += slab[(long)s * per + q];
+  if (col == KK) dbias[o] = a;
+  else dW[((long)o * Cin + ci) * k + j] = a;
 }
 
 // ------------------------------------------------------------------------------ layout helpers
@@ -595,7 +592,7 @@ static int convblock_bwd(const void* dout, int dout_ncl, const uint8_t* argmax, 
     conv_wgrad_kernel<CW><<<tiles * w.S, kThreads, lds, s>>>((const T*)dy, (const T*)x, slab, R, L, cin_pad, KK, Cout, pad, w.kper,
                                                             tiles_n, tiles, vec_dy, vec_x);
     EMB_CHECK_LAUNCH();
-    const long n = (long)Cout * Cin * k + Cout;
+    const long n = (long)Cout * (KK + 1);
     conv_wgrad_reduce_kernel<P><<<(int)((n + 255) / 256), 256, 0, s>>>(slab, w.S, Cout, Cin, cin_pad, k, (P*)dW, (P*)dbias);
     EMB_CHECK_LAUNCH();
   }

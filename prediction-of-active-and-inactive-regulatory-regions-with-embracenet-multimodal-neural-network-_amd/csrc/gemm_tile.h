@@ -97,7 +97,7 @@ template <typename T, typename P> struct EpiLinear {
 template <class Cfg, class XfA, class Epi>
 __device__ __forceinline__ void gemm_tile(const GemmOperand<typename Cfg::T>& A, const GemmOperand<typename Cfg::T>& Bm,
                                           int M, int N, int K, int tm, int tn, XfA xfa, int ones_row_b, const Epi& epi,
-                                          char* arena) {
+                                          char* arena, int k_begin = 0) {
   using T = typename Cfg::T;
   using Mm = typename Cfg::M;
   using Acc = typename Mm::Acc;
@@ -106,7 +106,7 @@ __device__ __forceinline__ void gemm_tile(const GemmOperand<typename Cfg::T>& A,
   zero_acc<Cfg>(acc);
   Stager<T, Cfg::AKM, Cfg::BM, Cfg::BK, XfA> sa{A.ptr, A.code, A.ld, row0, M, K, A.vec_ok, xfa, -1};
   Stager<T, Cfg::BKM, Cfg::BN, Cfg::BK, XfNone> sb{Bm.ptr, nullptr, Bm.ld, col0, N, K, Bm.vec_ok, XfNone{}, ones_row_b};
-  gemm_mainloop<Cfg>(sa, sb, K, arena, acc);
+  gemm_mainloop<Cfg>(sa, sb, K, arena, acc, k_begin);   // reduction range [k_begin, K)
   Acc* cs = reinterpret_cast<Acc*>(arena);
   reduce_to_slab<Cfg>(acc, cs);
   const int ncols_total = N + (ones_row_b >= 0 ? 1 : 0);

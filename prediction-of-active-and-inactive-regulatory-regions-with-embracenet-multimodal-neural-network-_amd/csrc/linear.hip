@@ -71,6 +71,8 @@ template <typename T> struct LinBwdArgs {
   XfLinearMask xf;
   int B, K, N;
   int end_dgrad, tiles_n_d, tiles_n_w, nblocks;
+  int S, kper, tiles_w;      // wgrad split over the batch: S slices of kper rows; S == 1 -> direct store
+  P* slab;                   // [S][N][K+1] partial sums (S > 1)
   bool vec_dx, vec_dw;
 };
 
@@ -82,16 +84,34 @@ template <typename T> __global__ __launch_bounds__(kThreads) void linear_bwd_ker
     const int tile = xcd_remap(bid, a.end_dgrad);
     EpiStore<T> epi{a.dX, (long)a.K, nullptr, a.K, a.vec_dx};
     gemm_tile<typename LinCfg<T>::D>(a.dY_rm, a.Wk, a.B, a.K, a.N, tile / a.tiles_n_d, tile % a.tiles_n_d, a.xf, -1, epi, arena);
-  } else {                   // dW[N,K] = dZ^T[N,B] . X[B,K], db = dZ^T . 1
+  } else if (a.S == 1) {     // dW[N,K] = dZ^T[N,B] . X[B,K], db = dZ^T . 1
     const int tile = xcd_remap(bid - a.end_dgrad, a.nblocks - a.end_dgrad);
     EpiStore<P> epi{a.dW, (long)a.K, a.db, a.K, a.vec_dw};
     gemm_tile<typename LinCfg<T>::W>(a.dY_km, a.Xk, a.N, a.K, a.B, tile / a.tiles_n_w, tile % a.tiles_n_w, a.xf, a.K, epi, arena);
+  } else {                   // few output tiles, long batch: slice the batch, partial sums to the slab
+    const int w = bid - a.end_dgrad, s = w / a.tiles_w, tile = w % a.tiles_w;
+    const int k_begin = s * a.kper, k_end = min(a.B, k_begin + a.kper);
+    EpiStore<P> epi{a.slab + (long)s * a.N * (a.K + 1), (long)(a.K + 1), nullptr, a.K + 1, false};
+    gemm_tile<typename LinCfg<T>::W>(a.dY_km, a.Xk, a.N, a.K, k_end, tile / a.tiles_n_w, tile % a.tiles_n_w, a.xf, a.K, epi, arena, k_begin);
   }
+}
+
+// dW[n][k], db[n] from the slab, slices summed in order (deterministic)
+template <typename P>
+__global__ void linear_wgrad_reduce_kernel(const P* __restrict__ slab, int S, int N, int K, P* __restrict__ dW, P* __restrict__ db) {
+  const long per = (long)N * (K + 1);
+  const long q = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (q >= per) return;
+  P acc = 0;
+  for (int s = 0; s < S; ++s) acc += slab[(long)s * per + q];
+  const int n = (int)(q / (K + 1)), k = (int)(q % (K + 1));
+  if (k == K) db[n] = acc;
+  else dW[(long)n * K + k] = acc;
 }
 
 template <typename T>
 static int linear_bwd_dispatch(const void* dY, const uint8_t* mask, const void* X, const void* W, void* dX, void* dW, void* db,
-                               int relu, float dropout_p, int B, int K, int N, hipStream_t s) {
+                               int relu, float dropout_p, void* ws, int64_t ws_bytes, int B, int K, int N, hipStream_t s) {
   using P = typename AccOf<T>::type;
   using CD = typename LinCfg<T>::D;
   using CW = typename LinCfg<T>::W;
@@ -109,7 +129,21 @@ static int linear_bwd_dispatch(const void* dY, const uint8_t* mask, const void* 
   a.tiles_n_d = cdiv(K, CD::BN);
   a.end_dgrad = dX ? cdiv(B, CD::BM) * a.tiles_n_d : 0;
   a.tiles_n_w = cdiv(K + 1, CW::BN);
-  a.nblocks = a.end_dgrad + cdiv(N, CW::BM) * a.tiles_n_w;
+  a.tiles_w = cdiv(N, CW::BM) * a.tiles_n_w;
+  // split the batch when the output is only a few tiles (FFNN / post / head layers) and scratch is available
+  a.S = 1; a.kper = B; a.slab = (P*)ws;
+  if (ws != nullptr && a.tiles_w < 64 && B >= 4 * CW::BK) {
+    int S = 256 / a.tiles_w;
+    const int smax = B / (2 * CW::BK);
+    if (S > smax) S = smax;
+    const int64_t per = (int64_t)N * (K + 1) * (int64_t)sizeof(P);
+    if ((int64_t)S * per > ws_bytes) S = (int)(ws_bytes / per);
+    if (S > 1) {
+      a.kper = cdiv(cdiv(B, S), CW::BK) * CW::BK;
+      a.S = cdiv(B, a.kper);
+    }
+  }
+  a.nblocks = a.end_dgrad + a.tiles_w * a.S;
   a.vec_dx = (K % 4 == 0) && aligned16(dX);
   a.vec_dw = (K % 4 == 0) && aligned16(dW);
   constexpr int lds = gemm_tile_lds<CD>() > gemm_tile_lds<CW>() ? gemm_tile_lds<CD>() : gemm_tile_lds<CW>();
@@ -120,6 +154,11 @@ static int linear_bwd_dispatch(const void* dY, const uint8_t* mask, const void* 
   }
   linear_bwd_kernel<T><<<a.nblocks, kThreads, lds, s>>>(a);
   EMB_CHECK_LAUNCH();
+  if (a.S > 1) {
+    const long per = (long)N * (K + 1);
+    linear_wgrad_reduce_kernel<P><<<(int)((per + 255) / 256), 256, 0, s>>>(a.slab, a.S, N, K, (P*)dW, (P*)db);
+    EMB_CHECK_LAUNCH();
+  }
   return EMB_OK;
 }
 
@@ -153,15 +192,16 @@ extern "C" int emb_linear_fwd(const void* X, const void* W, const void* b, void*
 }
 
 extern "C" int emb_linear_bwd(const void* dY, const uint8_t* mask, const void* X, const void* W, void* dX, void* dW, void* db,
-                              int relu, float dropout_p, int B, int K, int N, int dtype, emb_stream_t stream) {
+                              int relu, float dropout_p, void* workspace, int64_t workspace_bytes, int B, int K, int N,
+                              int dtype, emb_stream_t stream) {
   EMB_CHECK_ARG(dY && X && W && dW && db, "emb_linear_bwd: null pointer");
   EMB_CHECK_ARG(B > 0 && K > 0 && N > 0, "emb_linear_bwd: bad dims B=%d K=%d N=%d", B, K, N);
   EMB_CHECK_ARG(mask || (!relu && dropout_p == 0.f), "emb_linear_bwd: mask required when relu or dropout is on");
   hipStream_t s = (hipStream_t)stream;
   switch (dtype) {
-    case EMB_F32: return emb::linear_bwd_dispatch<float>(dY, mask, X, W, dX, dW, db, relu, dropout_p, B, K, N, s);
-    case EMB_BF16: return emb::linear_bwd_dispatch<__bf16>(dY, mask, X, W, dX, dW, db, relu, dropout_p, B, K, N, s);
-    case EMB_F64: return emb::linear_bwd_dispatch<double>(dY, mask, X, W, dX, dW, db, relu, dropout_p, B, K, N, s);
+    case EMB_F32: return emb::linear_bwd_dispatch<float>(dY, mask, X, W, dX, dW, db, relu, dropout_p, workspace, workspace_bytes, B, K, N, s);
+    case EMB_BF16: return emb::linear_bwd_dispatch<__bf16>(dY, mask, X, W, dX, dW, db, relu, dropout_p, workspace, workspace_bytes, B, K, N, s);
+    case EMB_F64: return emb::linear_bwd_dispatch<double>(dY, mask, X, W, dX, dW, db, relu, dropout_p, workspace, workspace_bytes, B, K, N, s);
   }
   emb::set_error("emb_linear_bwd: unsupported dtype %d", dtype);
   return EMB_ERR_DTYPE;

@@ -276,6 +276,159 @@ extern "C" int emb_counter_add(uint64_t* counter, uint64_t inc, emb_stream_t str
   return EMB_OK;
 }
 
+// ------------------------------------------------------------------- multi-tensor optimizer launch
+// One launch updates up to kMaxTensors parameter tensors (the reference's models have <= 34).  The pointer
+// table travels BY VALUE in the kernel argument (baked into a hipGraph node at capture time, rebuilt for free
+// on every eager call) and is first copied to LDS, so that it is never indexed dynamically in the kernarg
+// segment (see the hipcc note in embrace_bwd.hip).
+namespace emb {
+constexpr int kMaxTensors = 40;
+constexpr int kChunk = 1024;   // elements per block
+template <typename P> struct MultiArgs {
+  P* p[kMaxTensors];
+  const P* g[kMaxTensors];
+  P* m[kMaxTensors];
+  P* v[kMaxTensors];
+  __bf16* sh[kMaxTensors];
+  long long n[kMaxTensors];
+  long long blk_end[kMaxTensors];
+  long long count;
+};
+enum { OPT_ADAM = 0, OPT_RMSPROP = 1, OPT_NADAM = 2 };
+struct Hyper {
+  double lr, b1, b2, eps, wd, alpha, sdecay;
+  unsigned long long step_val;
+  const uint64_t* step_dev;
+  double* m_schedule;
+};
+
+template <typename P, int OPT>
+__global__ __launch_bounds__(256) void multi_opt_kernel(const MultiArgs<P> args, const Hyper h) {
+  __shared__ MultiArgs<P> a;
+  {
+    const unsigned long long* src = reinterpret_cast<const unsigned long long*>(&args);
+    unsigned long long* dst = reinterpret_cast<unsigned long long*>(&a);
+    for (int i = threadIdx.x; i < (int)(sizeof(MultiArgs<P>) / 8); i += 256) dst[i] = src[i];
+  }
+  __syncthreads();
+  int t = 0;
+  while (t < (int)a.count - 1 && (long long)blockIdx.x >= a.blk_end[t]) ++t;
+  const long long first_blk = t == 0 ? 0 : a.blk_end[t - 1];
+  const long long base = ((long long)blockIdx.x - first_blk) * kChunk;
+  P* p = a.p[t];
+  const P* g = a.g[t];
+  P* m = a.m[t];
+  P* v = a.v[t];
+  __bf16* sh = a.sh[t];
+  const long long n = a.n[t];
+  const uint64_t step = h.step_val + (h.step_dev ? *h.step_dev : 0);
+  const double td = (double)step;
+  P c1 = 0, c2 = 0, bc2s = 1;
+  if (OPT == OPT_ADAM) {
+    c1 = (P)(h.lr / (1.0 - pow(h.b1, td)));
+    bc2s = (P)sqrt(1.0 - pow(h.b2, td));
+  } else if (OPT == OPT_NADAM) {
+    const double mu_t = h.b1 * (1.0 - 0.5 * pow(0.96, td * h.sdecay));
+    const double mu_n = h.b1 * (1.0 - 0.5 * pow(0.96, (td + 1.0) * h.sdecay));
+    const double ms_new = h.m_schedule[(step + 1) & 1] * mu_t, ms_next = ms_new * mu_n;
+    c1 = (P)(h.lr * (1.0 - mu_t) / (1.0 - ms_new));
+    c2 = (P)(h.lr * mu_n / (1.0 - ms_next));
+    bc2s = (P)sqrt(1.0 - pow(h.b2, td));
+    if (blockIdx.x == 0 && threadIdx.x == 0) h.m_schedule[step & 1] = ms_new;
+  }
+  const P pb1 = (P)h.b1, pb2 = (P)h.b2, omb1 = (P)(1.0 - h.b1), omb2 = (P)(1.0 - h.b2), pwd = (P)h.wd, peps = (P)h.eps;
+  const P pa = (P)h.alpha, oma = (P)(1.0 - h.alpha), plr = (P)h.lr;
+#pragma unroll
+  for (int u = 0; u < kChunk / 256; ++u) {
+    const long long i = base + u * 256 + threadIdx.x;
+    if (i >= n) break;
+    P pi = p[i];
+    const P gi = g[i] + pwd * pi;
+    if (OPT == OPT_ADAM) {
+      const P mi = m[i] + (gi - m[i]) * omb1;
+      const P vi = v[i] * pb2 + gi * gi * omb2;
+      pi -= c1 * (mi / (sqrt(vi) / bc2s + peps));
+      m[i] = mi; v[i] = vi;
+    } else if (OPT == OPT_RMSPROP) {
+      const P si = v[i] * pa + gi * gi * oma;
+      pi -= plr * (gi / (sqrt(si) + peps));
+      v[i] = si;
+    } else {
+      const P mi = m[i] * pb1 + gi * omb1;
+      const P vi = v[i] * pb2 + gi * gi * omb2;
+      const P denom = sqrt(vi) / bc2s + peps;
+      pi -= c1 * (gi / denom);
+      pi -= c2 * (mi / denom);
+      m[i] = mi; v[i] = vi;
+    }
+    p[i] = pi;
+    if (sh) sh[i] = (__bf16)(float)pi;
+  }
+}
+
+template <typename P, int OPT>
+static int multi_launch(void* const* params, const void* const* grads, void* const* s1, void* const* s2, void* const* shadows,
+                        const int64_t* sizes, int ntensors, const Hyper& h, hipStream_t s) {
+  for (int off = 0; off < ntensors; off += kMaxTensors) {
+    const int cnt = ntensors - off < kMaxTensors ? ntensors - off : kMaxTensors;
+    MultiArgs<P> a;
+    long long blocks = 0;
+    for (int i = 0; i < kMaxTensors; ++i) {
+      const int j = off + (i < cnt ? i : 0);
+      a.p[i] = (P*)params[j];
+      a.g[i] = (const P*)grads[j];
+      a.m[i] = s1 ? (P*)s1[j] : nullptr;
+      a.v[i] = s2 ? (P*)s2[j] : nullptr;
+      a.sh[i] = shadows ? (__bf16*)shadows[j] : nullptr;
+      a.n[i] = i < cnt ? sizes[j] : 0;
+      if (i < cnt) blocks += (sizes[j] + kChunk - 1) / kChunk;
+      a.blk_end[i] = blocks;
+    }
+    a.count = cnt;
+    if (blocks == 0) continue;
+    multi_opt_kernel<P, OPT><<<(int)blocks, 256, 0, s>>>(a, h);
+    EMB_CHECK_LAUNCH();
+  }
+  return EMB_OK;
+}
+}  // namespace emb
+
+extern "C" int emb_adam_step_multi(void* const* params, const void* const* grads, void* const* exp_avg, void* const* exp_avg_sq,
+                                   void* const* bf16_shadows, const int64_t* sizes, int ntensors, double lr, double beta1,
+                                   double beta2, double eps, double weight_decay, uint64_t step_val, const uint64_t* step_dev,
+                                   int dtype, emb_stream_t stream) {
+  EMB_CHECK_ARG(params && grads && exp_avg && exp_avg_sq && sizes && ntensors >= 0, "emb_adam_step_multi: bad argument");
+  const Hyper h{lr, beta1, beta2, eps, weight_decay, 0.0, 0.0, step_val, step_dev, nullptr};
+  if (dtype == EMB_F64) return multi_launch<double, OPT_ADAM>(params, grads, exp_avg, exp_avg_sq, bf16_shadows, sizes, ntensors, h, (hipStream_t)stream);
+  if (dtype == EMB_F32 || dtype == EMB_BF16) return multi_launch<float, OPT_ADAM>(params, grads, exp_avg, exp_avg_sq, bf16_shadows, sizes, ntensors, h, (hipStream_t)stream);
+  set_error("emb_adam_step_multi: unsupported dtype %d", dtype);
+  return EMB_ERR_DTYPE;
+}
+
+extern "C" int emb_rmsprop_step_multi(void* const* params, const void* const* grads, void* const* square_avg,
+                                      void* const* bf16_shadows, const int64_t* sizes, int ntensors, double lr, double alpha,
+                                      double eps, double weight_decay, int dtype, emb_stream_t stream) {
+  EMB_CHECK_ARG(params && grads && square_avg && sizes && ntensors >= 0, "emb_rmsprop_step_multi: bad argument");
+  const Hyper h{lr, 0.0, 0.0, eps, weight_decay, alpha, 0.0, 0, nullptr, nullptr};
+  if (dtype == EMB_F64) return multi_launch<double, OPT_RMSPROP>(params, grads, nullptr, square_avg, bf16_shadows, sizes, ntensors, h, (hipStream_t)stream);
+  if (dtype == EMB_F32 || dtype == EMB_BF16) return multi_launch<float, OPT_RMSPROP>(params, grads, nullptr, square_avg, bf16_shadows, sizes, ntensors, h, (hipStream_t)stream);
+  set_error("emb_rmsprop_step_multi: unsupported dtype %d", dtype);
+  return EMB_ERR_DTYPE;
+}
+
+extern "C" int emb_nadam_step_multi(void* const* params, const void* const* grads, void* const* exp_avg, void* const* exp_avg_sq,
+                                    double* m_schedule, void* const* bf16_shadows, const int64_t* sizes, int ntensors, double lr,
+                                    double beta1, double beta2, double eps, double weight_decay, double schedule_decay,
+                                    uint64_t step_val, const uint64_t* step_dev, int dtype, emb_stream_t stream) {
+  EMB_CHECK_ARG(params && grads && exp_avg && exp_avg_sq && m_schedule && sizes && ntensors >= 0, "emb_nadam_step_multi: bad argument");
+  EMB_CHECK_ARG(ntensors <= emb::kMaxTensors, "emb_nadam_step_multi: at most %d tensors per call (shared m_schedule)", emb::kMaxTensors);
+  const Hyper h{lr, beta1, beta2, eps, weight_decay, 0.0, schedule_decay, step_val, step_dev, m_schedule};
+  if (dtype == EMB_F64) return multi_launch<double, OPT_NADAM>(params, grads, exp_avg, exp_avg_sq, bf16_shadows, sizes, ntensors, h, (hipStream_t)stream);
+  if (dtype == EMB_F32 || dtype == EMB_BF16) return multi_launch<float, OPT_NADAM>(params, grads, exp_avg, exp_avg_sq, bf16_shadows, sizes, ntensors, h, (hipStream_t)stream);
+  set_error("emb_nadam_step_multi: unsupported dtype %d", dtype);
+  return EMB_ERR_DTYPE;
+}
+
 // ------------------------------------------------------------------------------ library plumbing
 #include <cstdarg>
 #include <cstdio>

@@ -28,6 +28,51 @@ def _as(t, dtype):
     return t if t.is_contiguous() else t.contiguous()
 
 
+import weakref
+
+# bf16 (or other compute-dtype) copies of master weights.  Kept per Parameter OBJECT (keyed by id, guarded by a
+# weak reference -- tensors cannot be WeakKeyDictionary keys because == is elementwise); refreshed when the
+# parameter's version counter or storage changes (torch optimizers), written in place by the fused optimizers
+# (optim.py passes the registered shadow to the update kernel, so no cast kernel runs in steady state).
+_SHADOWS = {}
+
+
+def _shadow_entry(w):
+    ent = _SHADOWS.get(id(w))
+    if ent is not None and ent[0]() is not w:
+        del _SHADOWS[id(w)]
+        ent = None
+    return ent
+
+
+def weight_as(w, T):
+    """`w` viewed in compute dtype T (contiguous).  Same dtype: the parameter itself."""
+    if w.dtype == T:
+        wd = w.detach()
+        return wd if wd.is_contiguous() else wd.contiguous()
+    ent = _shadow_entry(w)
+    key = (w._version, w.data_ptr(), tuple(w.shape), T)
+    if ent is not None and ent[1] == key:
+        return ent[2]
+    out = ent[2] if (ent is not None and ent[2].shape == w.shape and ent[2].dtype == T and ent[2].device == w.device) else None
+    sh = cast(w.detach(), T, out=out)
+    if len(_SHADOWS) > 4096:                       # drop entries of parameters that no longer exist
+        for k in [k for k, v in _SHADOWS.items() if v[0]() is None]:
+            del _SHADOWS[k]
+    _SHADOWS[id(w)] = (weakref.ref(w), key, sh)
+    return sh
+
+
+def shadow_lookup(w):
+    """bf16 shadow registered for parameter `w` (None if there is none or it belongs to other storage)."""
+    ent = _shadow_entry(w)
+    if ent is None or ent[2].dtype != torch.bfloat16:
+        return None
+    if ent[1][1] != w.data_ptr() or ent[1][2] != tuple(w.shape):
+        return None
+    return ent[2]
+
+
 def select_prep(p, avail, B, rng=None, device_dropout=False, status=None):
     """EmbraceNetMultimodal.py:63-76,178-184 + torch.multinomial's cdf -> cdf0[B] (fp32, device)."""
     _lib.require_cuda(p, avail)
@@ -58,7 +103,7 @@ class _EmbraceFn(torch.autograd.Function):
         d1 = x1.shape[1]
         c = w0.shape[0]
         x0c, x1c = _as(x0, T), _as(x1, T)
-        w0c, w1c = _as(w0.detach(), T), _as(w1.detach(), T)
+        w0c, w1c = weight_as(w0, T), weight_as(w1, T)
         b0c, b1c = _as(b0.detach(), P), _as(b1.detach(), P)
         E = torch.empty(B, c, dtype=T, device=x0.device)
         code = torch.empty(B, c, dtype=torch.uint8, device=x0.device)
@@ -115,7 +160,7 @@ class _LinearFn(torch.autograd.Function):
         P = PARAM_DTYPE[T]
         B, K = x.shape
         N = w.shape[0]
-        xc, wc, bc = _as(x, T), _as(w.detach(), T), _as(b.detach(), P)
+        xc, wc, bc = _as(x, T), weight_as(w, T), _as(b.detach(), P)
         y = torch.empty(B, N, dtype=T, device=x.device)
         need_mask = bool(relu) or dropout_p > 0
         mask = torch.empty(B, N, dtype=torch.uint8, device=x.device) if need_mask else None
@@ -137,8 +182,9 @@ class _LinearFn(torch.autograd.Function):
         dx = torch.empty(B, K, dtype=T, device=xc.device) if ctx.needs_input_grad[0] else None
         dw = torch.empty(N, K, dtype=P, device=xc.device)
         db = torch.empty(N, dtype=P, device=xc.device)
+        ws = _workspace(xc.device, 1 << 22)
         check(_lib.lib().emb_linear_bwd(ptr(dy), ptr(mask), ptr(xc), ptr(wc), ptr(dx), ptr(dw), ptr(db), int(relu),
-                                        dropout_p, B, K, N, DTYPE_CODE[T], stream()), "emb_linear_bwd")
+                                        dropout_p, ptr(ws), ws.numel(), B, K, N, DTYPE_CODE[T], stream()), "emb_linear_bwd")
         cast = lambda g, d: None if g is None else (g if g.dtype == d else g.to(d))
         return cast(dx, tx), cast(dw, tw), cast(db, tb), None, None, None, None, None
 
