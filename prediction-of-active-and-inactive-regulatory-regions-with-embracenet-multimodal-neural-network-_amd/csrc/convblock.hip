@@ -258,54 +258,54 @@ __global__ __launch_bounds__(256) void bn_relu_pool_kernel(const T* __restrict__
   }
 }
 
-// gradient reaching the BN output at (b, t, c0..c0+VEC): gather over the <= 5 pooling windows that contain t
-template <typename T, bool NCL_IN>
-__device__ __forceinline__ void gather_dz(const T* __restrict__ dout, const uint8_t* __restrict__ argmax, int b, int t, int c0,
-                                          int Lp, int C, float keep_scale, typename AccOf<T>::type (&dz)[Elem<T>::VEC]) {
-  using Acc = typename AccOf<T>::type;
-  constexpr int VEC = Elem<T>::VEC;
-  using V = typename Vec16<T>::type;
-#pragma unroll
-  for (int e = 0; e < VEC; ++e) dz[e] = 0;
-  const int p_lo = t >= kPoolK - 1 ? (t - (kPoolK - 1) + 1) / 2 : 0;
-  const int p_hi = min(Lp - 1, t / 2);
-  for (int p = p_lo; p <= p_hi; ++p) {
-    const int off = t - kPoolS * p;
-    const long nlc = ((long)b * Lp + p) * C + c0;
-    uint64_t am;
-    if (VEC == 8) am = *reinterpret_cast<const uint64_t*>(argmax + nlc);
-    else if (VEC == 4) am = *reinterpret_cast<const uint32_t*>(argmax + nlc);
-    else am = *reinterpret_cast<const uint16_t*>(argmax + nlc);
-    V g;
-    if (NCL_IN) {
-#pragma unroll
-      for (int e = 0; e < VEC; ++e) g[e] = dout[((long)b * C + c0 + e) * Lp + p];
-    } else {
-      g = *reinterpret_cast<const V*>(dout + nlc);
-    }
-#pragma unroll
-    for (int e = 0; e < VEC; ++e) {
-      const int a = (int)((am >> (8 * e)) & 0xFF);
-      if (a == off) dz[e] += (Acc)g[e] * (Acc)keep_scale;   // dropped entries carry bit 7 -> never equal to off
-    }
-  }
+// BatchNorm / pool / ReLU backward, pass 1.  One block = TT consecutive positions of one sequence, all channels.
+// The pooled gradient rows (and their argmax bytes) that can reach those positions are staged in LDS once;
+// dz[b,t,c] = sum over the <= 5 windows containing t whose argmax is t (deterministic gather, no atomics),
+// masked by ReLU.  dz is written to `dz_out` (the dy buffer) and its per-channel sums (dz, dz*xhat) to
+// bpart[blk][2][C].
+__host__ __device__ constexpr int pool_plo(int t) { return t >= kPoolK - 1 ? (t - (kPoolK - 1) + 1) / 2 : 0; }
+
+template <typename T> static int bn_bwd_tile(int C) {
+  int TT = 64;
+  while (TT > 8 && (size_t)(TT / 2 + 5) * C * (sizeof(T) + 1) > 40 * 1024) TT >>= 1;
+  return TT;
 }
 
-// pass 1 of BatchNorm backward: per-block partial sums of dz and dz * xhat  -> bpart[blk][2][C]
 template <typename T, bool NCL_IN>
-__global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const T* __restrict__ dout, const uint8_t* __restrict__ argmax,
-                                                            const T* __restrict__ y, const typename AccOf<T>::type* __restrict__ stats,
-                                                            typename AccOf<T>::type* __restrict__ bpart, int B, int L, int Lp, int C,
-                                                            float keep_scale, int rows_per_block) {
+__global__ __launch_bounds__(256) void bn_bwd_dz_kernel(const T* __restrict__ dout, const uint8_t* __restrict__ argmax,
+                                                        const T* __restrict__ y, const typename AccOf<T>::type* __restrict__ stats,
+                                                        T* __restrict__ dz_out, typename AccOf<T>::type* __restrict__ bpart, int L,
+                                                        int Lp, int C, float keep_scale, int TT, int tiles_per_seq) {
   using Acc = typename AccOf<T>::type;
   constexpr int VEC = Elem<T>::VEC;
   using V = typename Vec16<T>::type;
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  Acc* red = reinterpret_cast<Acc*>(smem);   // [TY][2][C]
+  const int b = blockIdx.x / tiles_per_seq, t0 = (blockIdx.x % tiles_per_seq) * TT;
+  const int t_end = min(L, t0 + TT);
+  const int P0 = pool_plo(t0), P1 = min(Lp - 1, (t_end - 1) / 2), NP = P1 - P0 + 1;   // NP <= TT/2 + 5
+  const int NPmax = TT / 2 + 5;
+  T* dsm = reinterpret_cast<T*>(smem);                                   // [NPmax][C]
+  uint8_t* asm_ = reinterpret_cast<uint8_t*>(smem) + (size_t)NPmax * C * sizeof(T);   // [NPmax][C]
   const int TX = C / VEC, TY = 256 / TX;
   const int tx = threadIdx.x % TX, ty = threadIdx.x / TX;
+  if (NP > 0) {
+    const long nlc0 = ((long)b * Lp + P0) * C;
+    const int nvec = NP * C / VEC;
+    for (int i = threadIdx.x; i < nvec; i += 256) {
+      if (!NCL_IN) *reinterpret_cast<V*>(dsm + (long)i * VEC) = *reinterpret_cast<const V*>(dout + nlc0 + (long)i * VEC);
+      if (VEC == 8) *reinterpret_cast<uint64_t*>(asm_ + (long)i * VEC) = *reinterpret_cast<const uint64_t*>(argmax + nlc0 + (long)i * VEC);
+      else if (VEC == 4) *reinterpret_cast<uint32_t*>(asm_ + (long)i * VEC) = *reinterpret_cast<const uint32_t*>(argmax + nlc0 + (long)i * VEC);
+      else *reinterpret_cast<uint16_t*>(asm_ + (long)i * VEC) = *reinterpret_cast<const uint16_t*>(argmax + nlc0 + (long)i * VEC);
+    }
+    if (NCL_IN) {   // dout[b][c][p]: p contiguous
+      for (int i = threadIdx.x; i < NP * C; i += 256) {
+        const int c = i / NP, pp = i % NP;
+        dsm[(long)pp * C + c] = dout[((long)b * C + c) * Lp + P0 + pp];
+      }
+    }
+  }
+  __syncthreads();
   const int c0 = tx * VEC;
-  const long R = (long)B * L;
   Acc s1[VEC], s2[VEC], mean[VEC], inv[VEC], sc[VEC], sh[VEC];
 #pragma unroll
   for (int e = 0; e < VEC; ++e) {
@@ -313,20 +313,40 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const T* __restrict_
     mean[e] = stats[c0 + e]; inv[e] = stats[C + c0 + e]; sc[e] = stats[2 * C + c0 + e]; sh[e] = stats[3 * C + c0 + e];
   }
   if (ty < TY) {
-    const long r_begin = (long)blockIdx.x * rows_per_block;
-    for (long r = r_begin + ty; r < r_begin + rows_per_block && r < R; r += TY) {
-      const int b = (int)(r / L), t = (int)(r % L);
+    for (int t = t0 + ty; t < t_end; t += TY) {
       Acc dz[VEC];
-      gather_dz<T, NCL_IN>(dout, argmax, b, t, c0, Lp, C, keep_scale, dz);
+#pragma unroll
+      for (int e = 0; e < VEC; ++e) dz[e] = 0;
+      const int p_lo = pool_plo(t), p_hi = min(Lp - 1, t / 2);
+      for (int p = p_lo; p <= p_hi; ++p) {
+        const int off = t - kPoolS * p;
+        const long li = (long)(p - P0) * C + c0;
+        const V g = *reinterpret_cast<const V*>(dsm + li);
+        uint64_t am;
+        if (VEC == 8) am = *reinterpret_cast<const uint64_t*>(asm_ + li);
+        else if (VEC == 4) am = *reinterpret_cast<const uint32_t*>(asm_ + li);
+        else am = *reinterpret_cast<const uint16_t*>(asm_ + li);
+#pragma unroll
+        for (int e = 0; e < VEC; ++e)
+          if ((int)((am >> (8 * e)) & 0xFF) == off) dz[e] += (Acc)g[e] * (Acc)keep_scale;   // dropped: bit 7 set, never equal
+      }
+      const long r = (long)b * L + t;
       const V yv = *reinterpret_cast<const V*>(y + r * C + c0);
+      V o;
 #pragma unroll
       for (int e = 0; e < VEC; ++e) {
         const Acc yy = (Acc)yv[e];
         const Acc g = (yy * sc[e] + sh[e]) > (Acc)0 ? dz[e] : (Acc)0;   // ReLU mask
+        o[e] = (T)g;
         s1[e] += g;
         s2[e] += g * ((yy - mean[e]) * inv[e]);
       }
+      *reinterpret_cast<V*>(dz_out + r * C + c0) = o;
     }
+  }
+  __syncthreads();   // LDS is reused for the block reduction
+  Acc* red = reinterpret_cast<Acc*>(smem);   // [TY][2][C]
+  if (ty < TY) {
 #pragma unroll
     for (int e = 0; e < VEC; ++e) {
       red[((long)ty * 2 + 0) * C + c0 + e] = s1[e];
@@ -370,36 +390,37 @@ __global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(const P* __restric
   }
 }
 
-// pass 2: dy = scale * (dz - mean(dz) - xhat * mean(dz*xhat))   (training);   dy = scale * dz   (eval)
-template <typename T, bool NCL_IN>
-__global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const T* __restrict__ dout, const uint8_t* __restrict__ argmax,
-                                                           const T* __restrict__ y, const typename AccOf<T>::type* __restrict__ stats,
-                                                           const typename AccOf<T>::type* __restrict__ coef, T* __restrict__ dy,
-                                                           int B, int L, int Lp, int C, float keep_scale, int training) {
+// pass 2 (in place on the dz buffer): dy = scale * (dz - mean(dz) - xhat * mean(dz*xhat))  (training) or scale * dz (eval),
+// i.e. per channel dy = A*dz + Bc*y + D.  Thread (tx, ty): fixed channel vector, rows ty, ty+TY, ... of its block.
+template <typename T>
+__global__ __launch_bounds__(256) void bn_bwd_affine_kernel(const T* __restrict__ y, const typename AccOf<T>::type* __restrict__ stats,
+                                                            const typename AccOf<T>::type* __restrict__ coef, T* __restrict__ dy,
+                                                            int R, int C, int training, int rows_per_block) {
   using Acc = typename AccOf<T>::type;
   constexpr int VEC = Elem<T>::VEC;
   using V = typename Vec16<T>::type;
-  const int cv = C / VEC;
-  const long total = (long)B * L * cv;
-  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= total) return;
-  const int c0 = (int)(i % cv) * VEC;
-  const long r = i / cv;
-  const int b = (int)(r / L), t = (int)(r % L);
-  Acc dz[VEC];
-  gather_dz<T, NCL_IN>(dout, argmax, b, t, c0, Lp, C, keep_scale, dz);
-  const V yv = *reinterpret_cast<const V*>(y + r * C + c0);
-  V o;
+  const int TX = C / VEC, TY = 256 / TX;
+  const int tx = threadIdx.x % TX, ty = threadIdx.x / TX;
+  if (ty >= TY) return;
+  const int c0 = tx * VEC;
+  Acc A[VEC], Bc[VEC], D[VEC];
 #pragma unroll
   for (int e = 0; e < VEC; ++e) {
-    const Acc yy = (Acc)yv[e];
-    const Acc sc = stats[2 * C + c0 + e], sh = stats[3 * C + c0 + e];
-    const Acc g = (yy * sc + sh) > (Acc)0 ? dz[e] : (Acc)0;
-    Acc d = g;
-    if (training) d = g - coef[c0 + e] - ((yy - stats[c0 + e]) * stats[C + c0 + e]) * coef[C + c0 + e];
-    o[e] = (T)(sc * d);
+    const Acc mean = stats[c0 + e], inv = stats[C + c0 + e], sc = stats[2 * C + c0 + e];
+    A[e] = sc;
+    Bc[e] = training ? -sc * coef[C + c0 + e] * inv : (Acc)0;
+    D[e] = training ? sc * (coef[C + c0 + e] * inv * mean - coef[c0 + e]) : (Acc)0;
   }
-  *reinterpret_cast<V*>(dy + r * C + c0) = o;
+  const int r_begin = blockIdx.x * rows_per_block, r_end = min(R, r_begin + rows_per_block);
+  for (int r = r_begin + ty; r < r_end; r += TY) {
+    const long off = (long)r * C + c0;
+    const V dzv = *reinterpret_cast<const V*>(dy + off);
+    const V yv = *reinterpret_cast<const V*>(y + off);
+    V o;
+#pragma unroll
+    for (int e = 0; e < VEC; ++e) o[e] = (T)(A[e] * (Acc)dzv[e] + Bc[e] * (Acc)yv[e] + D[e]);
+    *reinterpret_cast<V*>(dy + off) = o;
+  }
 }
 
 // ------------------------------------------------------------------------------------- wgrad
@@ -432,22 +453,30 @@ __global__ __launch_bounds__(kThreads) void conv_wgrad_kernel(const typename Cfg
   }
 }
 
-// dW[o][ci][j] (torch Conv1d layout, real channels only) and dbias[o] from the slabs, slices summed in order
+// dW[o][ci][j] (torch Conv1d layout, real channels only) and dbias[o] from the slabs.  Block = 16 slab elements x
+// 16 slice lanes: lane sl sums slices sl, sl+16, ...; the 16 lane sums are combined in lane order (deterministic).
 template <typename P>
-__global__ void conv_wgrad_reduce_kernel(const P* __restrict__ slab, int S, int Cout, int Cin, int cin_pad, int k,
-                                         P* __restrict__ dW, P* __restrict__ dbias) {
-  // one thread per SLAB element: the S reads of a wavefront are contiguous; the (small) result is scattered
+__global__ __launch_bounds__(256) void conv_wgrad_reduce_kernel(const P* __restrict__ slab, int S, int Cout, int Cin, int cin_pad,
+                                                                int k, P* __restrict__ dW, P* __restrict__ dbias) {
+  __shared__ P red[16][17];
   const int KK = k * cin_pad;
   const long per = (long)Cout * (KK + 1);
-  const long q = (long)blockIdx.x * blockDim.x + threadIdx.x;
-  if (q >= per) return;
-  const int o = (int)(q / (KK + 1)), col = (int)(q % (KK + 1));
-  const int j = col / cin_pad, ci = col % cin_pad;
-  if (col < KK && ci >= Cin) return;   // zero-padded input channel
+  const int qi = threadIdx.x & 15, sl = threadIdx.x >> 4;
+  const long q = (long)blockIdx.x * 16 + qi;
   P a = 0;
-  for (int s = 0; s < S; ++s) a += slab[(long)s * per + q];
-  if (col == KK) dbias[o] = a;
-  else dW[((long)o * Cin + ci) * k + j] = a;
+  if (q < per)
+    for (int s = sl; s < S; s += 16) a += slab[(long)s * per + q];
+  red[sl][qi] = a;
+  __syncthreads();
+  if (sl == 0 && q < per) {
+    P t = 0;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) t += red[i][qi];
+    const int o = (int)(q / (KK + 1)), col = (int)(q % (KK + 1));
+    const int j = col / cin_pad, ci = col % cin_pad;
+    if (col == KK) dbias[o] = t;
+    else if (ci < Cin) dW[((long)o * Cin + ci) * k + j] = t;
+  }
 }
 
 // ------------------------------------------------------------------------------ layout helpers
@@ -494,9 +523,8 @@ template <typename T> static ConvWs conv_workspace(int B, int L, int cin_pad, in
   const long R = (long)B * L;
   const int KK = k * cin_pad;
   w.tiles_m = cdiv((int)R, CF::BM);
-  const int TX = Cout / VEC, TY = 256 / (TX > 0 ? TX : 1);
-  w.rows_per_block = TY * 8;
-  w.nblk_bwd = cdiv((int)R, w.rows_per_block);
+  w.rows_per_block = bn_bwd_tile<T>(Cout);                 // TT positions of one sequence per block
+  w.nblk_bwd = B * cdiv(L, w.rows_per_block);
   const int tiles = cdiv(Cout, CW::BM) * cdiv(KK + 1, CW::BN);
   int S = 1024 / (tiles > 0 ? tiles : 1);
   const int max_s = (int)(R / (4 * CW::BK));
@@ -563,22 +591,23 @@ static int convblock_bwd(const void* dout, int dout_ncl, const uint8_t* argmax, 
   P* coef = (P*)(base + w.bwd_partial);
   P* slab = (P*)(base + w.bwd_partial + w.coef);
   {   // dgamma / dbeta are defined in eval mode too (x-hat then uses the running statistics)
-    const size_t sm = (size_t)(256 / (Cout / VEC)) * 2 * Cout * sizeof(P);
+    const int TT = w.rows_per_block, tiles_per_seq = cdiv(L, TT);
+    const int TY = 256 / (Cout / VEC);
+    size_t sm = (size_t)(TT / 2 + 5) * Cout * (sizeof(T) + 1);
+    const size_t sm_red = (size_t)TY * 2 * Cout * sizeof(P);
+    if (sm_red > sm) sm = sm_red;
+    sm = (sm + 15) & ~(size_t)15;
     if (dout_ncl)
-      bn_bwd_reduce_kernel<T, true><<<w.nblk_bwd, 256, sm, s>>>((const T*)dout, argmax, (const T*)y, (const P*)stats, bpart, B, L, Lp, Cout, keep_scale, w.rows_per_block);
+      bn_bwd_dz_kernel<T, true><<<w.nblk_bwd, 256, sm, s>>>((const T*)dout, argmax, (const T*)y, (const P*)stats, (T*)dy, bpart, L, Lp, Cout, keep_scale, TT, tiles_per_seq);
     else
-      bn_bwd_reduce_kernel<T, false><<<w.nblk_bwd, 256, sm, s>>>((const T*)dout, argmax, (const T*)y, (const P*)stats, bpart, B, L, Lp, Cout, keep_scale, w.rows_per_block);
+      bn_bwd_dz_kernel<T, false><<<w.nblk_bwd, 256, sm, s>>>((const T*)dout, argmax, (const T*)y, (const P*)stats, (T*)dy, bpart, L, Lp, Cout, keep_scale, TT, tiles_per_seq);
     EMB_CHECK_LAUNCH();
     bn_bwd_finalize_kernel<P><<<Cout, 256, 0, s>>>(bpart, w.nblk_bwd, Cout, (double)R, (P*)dgamma, (P*)dbeta, coef);
     EMB_CHECK_LAUNCH();
+    const int rpb = TY * 8;   // rows per block of the elementwise pass
+    bn_bwd_affine_kernel<T><<<cdiv(R, rpb), 256, 0, s>>>((const T*)y, (const P*)stats, coef, (T*)dy, R, Cout, training, rpb);
+    EMB_CHECK_LAUNCH();
   }
-  const long total = (long)R * (Cout / VEC);
-  const int grid = (int)((total + 255) / 256);
-  if (dout_ncl)
-    bn_bwd_apply_kernel<T, true><<<grid, 256, 0, s>>>((const T*)dout, argmax, (const T*)y, (const P*)stats, coef, (T*)dy, B, L, Lp, Cout, keep_scale, training);
-  else
-    bn_bwd_apply_kernel<T, false><<<grid, 256, 0, s>>>((const T*)dout, argmax, (const T*)y, (const P*)stats, coef, (T*)dy, B, L, Lp, Cout, keep_scale, training);
-  EMB_CHECK_LAUNCH();
   // wgrad: split over the B*L reduction, slices reduced in order
   {
     const int tiles_n = cdiv(KK + 1, CW::BN), tiles = cdiv(Cout, CW::BM) * tiles_n;
@@ -593,7 +622,7 @@ static int convblock_bwd(const void* dout, int dout_ncl, const uint8_t* argmax, 
                                                             tiles_n, tiles, vec_dy, vec_x);
     EMB_CHECK_LAUNCH();
     const long n = (long)Cout * (KK + 1);
-    conv_wgrad_reduce_kernel<P><<<(int)((n + 255) / 256), 256, 0, s>>>(slab, w.S, Cout, Cin, cin_pad, k, (P*)dW, (P*)dbias);
+    conv_wgrad_reduce_kernel<P><<<(int)((n + 15) / 16), 256, 0, s>>>(slab, w.S, Cout, Cin, cin_pad, k, (P*)dW, (P*)dbias);
     EMB_CHECK_LAUNCH();
   }
   if (dx != nullptr) {   // dgrad: the same conv-view GEMM on dy with flipped taps
