@@ -12,9 +12,12 @@
 // BatchNorm batch statistics come from per-tile partial sums written by the forward GEMM's epilogue and are
 // finalised in double; BN + ReLU + max-pool (+ dropout) is one elementwise pass; the backward recomputes the
 // pooled gradient by a deterministic gather (no atomics anywhere: results are bitwise reproducible).
+#include "conv_direct.h"
 #include "gemm_tile.h"
 
 namespace emb {
+
+template <typename T> constexpr int dtype_code() { return sizeof(T) == 2 ? EMB_BF16 : (sizeof(T) == 4 ? EMB_F32 : EMB_F64); }
 
 template <typename T> struct ConvCfg;
 template <> struct ConvCfg<__bf16> {
@@ -536,7 +539,12 @@ template <typename T> static ConvWs conv_workspace(int B, int L, int cin_pad, in
   w.S = S;
   w.kper = kper;
   auto al = [](size_t b) { return (b + 255) & ~(size_t)255; };
-  w.stat_partial = al((size_t)w.tiles_m * 2 * Cout * sizeof(P));
+  const int pad = (k - 1) / 2;
+  const int tiles_direct = conv_tiling(B, L, pad).tiles_m;          // direct kernels tile per sequence
+  const int S_direct = conv_wgrad_slices(B, L, pad, KK, Cout, dtype_code<T>());
+  const int tiles_stat = w.tiles_m > tiles_direct ? w.tiles_m : tiles_direct;
+  w.stat_partial = al((size_t)tiles_stat * 2 * Cout * sizeof(P));
+  if (S_direct > S) S = S_direct;
   w.bwd_partial = al((size_t)w.nblk_bwd * 2 * Cout * sizeof(P));
   w.coef = al((size_t)2 * Cout * sizeof(P));
   w.slab = al((size_t)S * Cout * (KK + 1) * sizeof(P));
@@ -557,11 +565,14 @@ static int convblock_fwd(const void* x, const void* wpack, const void* bias, con
   EMB_CHECK_ARG(cin_pad % VEC == 0 && Cout % VEC == 0, "emb_convblock_fwd: channels must be multiples of %d", VEC);
   const int R = B * L, KK = k * cin_pad, pad = (k - 1) / 2, Lp = (L - kPoolK) / kPoolS + 1;
   EMB_CHECK_ARG(Lp >= 1, "emb_convblock_fwd: sequence too short for the pooling window");
-  int rc;
-  if (Cout >= 64) rc = launch_conv_gemm<typename ConvCfg<T>::F64, true>(x, wpack, bias, y, ws, R, L, cin_pad, KK, Cout, pad, s);
-  else rc = launch_conv_gemm<typename ConvCfg<T>::F32, true>(x, wpack, bias, y, ws, R, L, cin_pad, KK, Cout, pad, s);
+  int tiles_m = conv_tiling(B, L, pad).tiles_m;
+  int rc = launch_conv_direct(dtype_code<T>(), true, x, wpack, bias, y, ws, B, L, cin_pad, KK, Cout, pad, s);
+  if (rc == 1) {   // activation tile does not fit in LDS: generic GEMM on the im2col view
+    if (Cout >= 64) rc = launch_conv_gemm<typename ConvCfg<T>::F64, true>(x, wpack, bias, y, ws, R, L, cin_pad, KK, Cout, pad, s);
+    else rc = launch_conv_gemm<typename ConvCfg<T>::F32, true>(x, wpack, bias, y, ws, R, L, cin_pad, KK, Cout, pad, s);
+    tiles_m = cdiv(R, Cout >= 64 ? ConvCfg<T>::F64::BM : ConvCfg<T>::F32::BM);
+  }
   if (rc != EMB_OK) return rc;
-  const int tiles_m = cdiv(R, Cout >= 64 ? ConvCfg<T>::F64::BM : ConvCfg<T>::F32::BM);
   bn_finalize_kernel<P><<<Cout, 256, 0, s>>>((const P*)ws, tiles_m, Cout, (double)R, (const P*)gamma, (const P*)beta, (P*)rmean,
                                            (P*)rvar, training, momentum, eps, (P*)stats);
   EMB_CHECK_LAUNCH();
@@ -608,27 +619,36 @@ static int convblock_bwd(const void* dout, int dout_ncl, const uint8_t* argmax, 
     bn_bwd_affine_kernel<T><<<cdiv(R, rpb), 256, 0, s>>>((const T*)y, (const P*)stats, coef, (T*)dy, R, Cout, training, rpb);
     EMB_CHECK_LAUNCH();
   }
-  // wgrad: split over the B*L reduction, slices reduced in order
+  // wgrad: reduction over all B*L rows, split into slices whose partial slabs are reduced in order
   {
-    const int tiles_n = cdiv(KK + 1, CW::BN), tiles = cdiv(Cout, CW::BM) * tiles_n;
-    const int vec_dy = (Cout % VEC == 0) && aligned16(dy), vec_x = (cin_pad % VEC == 0) && aligned16(x);
-    constexpr int lds = gemm_tile_lds<CW>();
-    static bool attr_set = false;
-    if (!attr_set && lds > 48 * 1024) {
-      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wgrad_kernel<CW>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-      attr_set = true;
-    }
-    conv_wgrad_kernel<CW><<<tiles * w.S, kThreads, lds, s>>>((const T*)dy, (const T*)x, slab, R, L, cin_pad, KK, Cout, pad, w.kper,
+    int S = conv_wgrad_slices(B, L, pad, KK, Cout, dtype_code<T>());
+    int rc = launch_conv_wgrad_direct(dtype_code<T>(), dy, x, slab, B, L, cin_pad, KK, Cout, pad, S, s);
+    if (rc == 1) {
+      const int tiles_n = cdiv(KK + 1, CW::BN), tiles = cdiv(Cout, CW::BM) * tiles_n;
+      const int vec_dy = (Cout % VEC == 0) && aligned16(dy), vec_x = (cin_pad % VEC == 0) && aligned16(x);
+      constexpr int lds = gemm_tile_lds<CW>();
+      static bool attr_set = false;
+      if (!attr_set && lds > 48 * 1024) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wgrad_kernel<CW>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        attr_set = true;
+      }
+      S = w.S;
+      conv_wgrad_kernel<CW><<<tiles * S, kThreads, lds, s>>>((const T*)dy, (const T*)x, slab, R, L, cin_pad, KK, Cout, pad, w.kper,
                                                             tiles_n, tiles, vec_dy, vec_x);
-    EMB_CHECK_LAUNCH();
+      EMB_CHECK_LAUNCH();
+    } else if (rc != EMB_OK) {
+      return rc;
+    }
     const long n = (long)Cout * (KK + 1);
-    conv_wgrad_reduce_kernel<P><<<(int)((n + 15) / 16), 256, 0, s>>>(slab, w.S, Cout, Cin, cin_pad, k, (P*)dW, (P*)dbias);
+    conv_wgrad_reduce_kernel<P><<<(int)((n + 15) / 16), 256, 0, s>>>(slab, S, Cout, Cin, cin_pad, k, (P*)dW, (P*)dbias);
     EMB_CHECK_LAUNCH();
   }
   if (dx != nullptr) {   // dgrad: the same conv-view GEMM on dy with flipped taps
-    int rc;
-    if (cin_pad >= 64) rc = launch_conv_gemm<typename ConvCfg<T>::F64, false>(dy, wflip, nullptr, dx, nullptr, R, L, Cout, k * Cout, cin_pad, pad, s);
-    else rc = launch_conv_gemm<typename ConvCfg<T>::F32, false>(dy, wflip, nullptr, dx, nullptr, R, L, Cout, k * Cout, cin_pad, pad, s);
+    int rc = launch_conv_direct(dtype_code<T>(), false, dy, wflip, nullptr, dx, nullptr, B, L, Cout, k * Cout, cin_pad, pad, s);
+    if (rc == 1) {
+      if (cin_pad >= 64) rc = launch_conv_gemm<typename ConvCfg<T>::F64, false>(dy, wflip, nullptr, dx, nullptr, R, L, Cout, k * Cout, cin_pad, pad, s);
+      else rc = launch_conv_gemm<typename ConvCfg<T>::F32, false>(dy, wflip, nullptr, dx, nullptr, R, L, Cout, k * Cout, cin_pad, pad, s);
+    }
     if (rc != EMB_OK) return rc;
   }
   return EMB_OK;
