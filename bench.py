@@ -112,6 +112,7 @@ def kernel_roofline(ea, wl, device):
     dW0, dW1 = torch.empty(c, d0, device=device, dtype=P), torch.empty(c, d1, device=device, dtype=P)
     db0, db1 = torch.empty(c, device=device, dtype=P), torch.empty(c, device=device, dtype=P)
     L, ptr, st, code_of = ea._lib.lib(), ea._lib.ptr, ea._lib.stream, ea._lib.DTYPE_CODE[T]
+    wsp = torch.empty(1 << 24, dtype=torch.uint8, device=device)
 
     def fwd():
         ea._lib.check(L.emb_embrace_fwd(ptr(x0), ptr(x1), ptr(w0c), ptr(b0), ptr(w1c), ptr(b1), ptr(cdf0), None, rng.seed,
@@ -119,7 +120,8 @@ def kernel_roofline(ea, wl, device):
 
     def bwd():
         ea._lib.check(L.emb_embrace_bwd(ptr(dE), ptr(code), ptr(x0), ptr(x1), ptr(w0c), ptr(w1c), ptr(dX0), ptr(dX1),
-                                        ptr(dW0), ptr(db0), ptr(dW1), ptr(db1), B, d0, d1, c, code_of, st()), "bwd")
+                                        ptr(dW0), ptr(db0), ptr(dW1), ptr(db1), ptr(wsp), wsp.numel(), B, d0, d1, c, code_of,
+                                        st()), "bwd")
     fwd()
     t_f, t_b = event_time_us(fwd, 200), event_time_us(bwd, 200)
     K = d0 + d1
@@ -176,6 +178,7 @@ def main():
     ap.add_argument("--backend", default=None, help="nccl (RCCL, default) or gloo (rehearsal on one GPU)")
     ap.add_argument("--cpu-baseline-seconds", type=float, default=15.0)
     ap.add_argument("--no-extras", action="store_true", help="skip roofline and cpu_baseline legs")
+    ap.add_argument("--roofline-only", action="store_true", help="only time the isolated kernels (used under rocprofv3 --pmc)")
     args = ap.parse_args()
 
     import embracenet_amd as ea
@@ -191,6 +194,11 @@ def main():
         wl["dtype"] = args.dtype
     B, Fin = wl["B"], wl["F"]
 
+    if args.roofline_only:
+        kern, dims = kernel_roofline(ea, wl, device)
+        print(json.dumps({"kernels": kern, "shapes": dims}), flush=True)
+        return
+
     torch.manual_seed(1234)                               # identical initial weights on every rank
     model = ea.EmbraceNetMultimodal(DictTrial(wl["hp"]), cell_line="A549", task="active_E_vs_inactive_E", device=device,
                                     in_features_FFNN=Fin)
@@ -202,25 +210,35 @@ def main():
     counts = torch.zeros(2, dtype=torch.int64, device=device)
     table = ea.metrics.StepTable(1, device)
     loss_slot, conf_slot = table.slot()
-    bucket = D.GradBucket(model.parameters())
     F = ea.functional
     model.train()
+    # N > 1: every gradient is a view of ONE flat buffer that the backward kernels write directly, so the
+    # data-parallel reduction is a single in-place RCCL all-reduce.  Two trailing slots carry the NEXT step's
+    # local (positives, rows): the global class counts a step needs before its loss are thus
+    # reduced one step ahead inside the gradient collective (labels are known when a batch is staged).
+    flat = D.FlatGrads(model.parameters(), extra=2) if world > 1 else None
+    local_counts = F.count_labels(y).to(torch.float32) if world > 1 else None
 
     def fwd_bwd():
-        opt.zero_grad(set_to_none=True)
+        if flat is None:
+            opt.zero_grad(set_to_none=True)
         out = model([x1, x2], is_training=True)
         loss = F.weighted_ce(out, y, class_counts=counts, global_counts=world > 1, confusion=conf_slot, loss_out=loss_slot)
         loss.backward()
 
-    def pre():                                            # class weights of the GLOBAL batch (labels known up front)
-        if world > 1:
-            F.count_labels(y, out=counts)
-            D.allreduce_counts(counts)
+    def reduce_grads():
+        flat.extra.copy_(local_counts)                    # next batch's labels (synthetic: the same batch)
+        flat.allreduce()
+        counts.copy_(flat.extra.round().to(torch.int64))
+
+    if world > 1:                                         # counts of the very first step
+        F.count_labels(y, out=counts)
+        D.allreduce_counts(counts)
 
     def eager_step():
-        pre()
         fwd_bwd()
-        bucket.allreduce()
+        if flat is not None:
+            reduce_grads()
         opt.step()
 
     side = torch.cuda.Stream()
@@ -247,9 +265,8 @@ def main():
                 opt.step()
 
             def step():
-                pre()
                 g_fb.replay()
-                bucket.allreduce()
+                reduce_grads()
                 g_opt.replay()
     else:
         step = eager_step

@@ -80,10 +80,13 @@ int emb_embrace_fwd(const void* X0, const void* X1, const void* W0, const void* 
 /* autograd of the above (loss.backward(), utils/training_models_multimodal.py:156):
  *   dD_m = dE * [idx == m] * [pre_m > 0];  dW_m = dD_m^T X_m;  db_m = sum_b dD_m;  dX_m = dD_m W_m
  *   dE [B,c] T, code [B,c] u8;  dX0 [B,d0] T, dX1 [B,d1] T (either may be NULL: not needed);
- *   dW0 [c,d0] P, db0 [c] P, dW1 [c,d1] P, db1 [c] P  (overwritten, not accumulated) */
+ *   dW0 [c,d0] P, db0 [c] P, dW1 [c,d1] P, db1 [c] P  (overwritten, not accumulated)
+ *   workspace (nullable): transient scratch; when given and c*d is only a few tiles, the weight gradients are split
+ *   over the batch into per-slice partial sums and reduced in a fixed order (second small launch). */
 int emb_embrace_bwd(const void* dE, const uint8_t* code, const void* X0, const void* X1, const void* W0,
-                    const void* W1, void* dX0, void* dX1, void* dW0, void* db0, void* dW1, void* db1, int B,
-                    int d0, int d1, int c, int dtype, emb_stream_t stream);
+                    const void* W1, void* dX0, void* dX1, void* dW0, void* db0, void* dW1, void* db1,
+                    void* workspace, int64_t workspace_bytes, int B, int d0, int d1, int c, int dtype,
+                    emb_stream_t stream);
 
 /* One layer of the post stack, EmbraceNetMultimodal.py:143-147 / :151 (also FFNN_pre.py:25-33):
  * Y = dropout(relu(X W^T + b)).   X [B,K] T, W [N,K] T, b [N] P, Y [B,N] T.

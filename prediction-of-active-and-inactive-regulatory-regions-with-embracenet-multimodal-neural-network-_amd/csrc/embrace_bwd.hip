@@ -39,6 +39,8 @@ template <typename T, typename OutT> struct BwdJob {
   int end;           // exclusive end of this job's block range
   int want;          // XfEmbraceMask::want
   int vec_b, vec_c;  // 16-byte loads of B / 4-wide stores of C legal
+  int S, kper, tiles;  // wgrad only: reduction (batch) split into S slices of kper rows; S == 1 -> direct store
+  OutT* slab;          // [S][M][N+1] partial sums when S > 1
 };
 
 template <typename T>
@@ -60,33 +62,65 @@ __global__ __launch_bounds__(kThreads) void embrace_bwd_kernel(const T* __restri
                   tile % dg1.tiles_n, XfEmbraceMask{(uint8_t)dg1.want}, -1,
                   EpiStore<T>{dg1.C, (long)dg1.N, nullptr, dg1.N, dg1.vec_c != 0}, arena);
   } else if (bid < wg1.end) {
-    const int tile = xcd_remap(bid - dg1.end, wg1.end - dg1.end);
-    gemm_tile<CW>(A, GemmOperand<T>{wg1.Bptr, nullptr, wg1.ldb, wg1.vec_b != 0}, wg1.M, wg1.N, wg1.K, tile / wg1.tiles_n,
-                  tile % wg1.tiles_n, XfEmbraceMask{(uint8_t)wg1.want}, wg1.N,
-                  EpiStore<P>{wg1.C, (long)wg1.N, wg1.extra, wg1.N, wg1.vec_c != 0}, arena);
+    const int wq = bid - dg1.end, sl = wq / wg1.tiles, tile = xcd_remap(wq % wg1.tiles, wg1.tiles);
+    const GemmOperand<T> Bop{wg1.Bptr, nullptr, wg1.ldb, wg1.vec_b != 0};
+    if (wg1.S == 1) {
+      gemm_tile<CW>(A, Bop, wg1.M, wg1.N, wg1.K, tile / wg1.tiles_n, tile % wg1.tiles_n, XfEmbraceMask{(uint8_t)wg1.want},
+                    wg1.N, EpiStore<P>{wg1.C, (long)wg1.N, wg1.extra, wg1.N, wg1.vec_c != 0}, arena);
+    } else {   // batch slice sl: partial sums (bias column included) to this slice's slab
+      const int k_begin = sl * wg1.kper, k_end = min(wg1.K, k_begin + wg1.kper);
+      gemm_tile<CW>(A, Bop, wg1.M, wg1.N, k_end, tile / wg1.tiles_n, tile % wg1.tiles_n, XfEmbraceMask{(uint8_t)wg1.want},
+                    wg1.N, EpiStore<P>{wg1.slab + (long)sl * wg1.M * (wg1.N + 1), (long)(wg1.N + 1), nullptr, wg1.N + 1, false},
+                    arena, k_begin);
+    }
   } else if (bid < dg0.end) {
     const int tile = xcd_remap(bid - wg1.end, dg0.end - wg1.end);
     gemm_tile<CD>(A, GemmOperand<T>{dg0.Bptr, nullptr, dg0.ldb, dg0.vec_b != 0}, dg0.M, dg0.N, dg0.K, tile / dg0.tiles_n,
                   tile % dg0.tiles_n, XfEmbraceMask{(uint8_t)dg0.want}, -1,
                   EpiStore<T>{dg0.C, (long)dg0.N, nullptr, dg0.N, dg0.vec_c != 0}, arena);
   } else {
-    const int tile = xcd_remap(bid - dg0.end, wg0.end - dg0.end);
-    gemm_tile<CW>(A, GemmOperand<T>{wg0.Bptr, nullptr, wg0.ldb, wg0.vec_b != 0}, wg0.M, wg0.N, wg0.K, tile / wg0.tiles_n,
-                  tile % wg0.tiles_n, XfEmbraceMask{(uint8_t)wg0.want}, wg0.N,
-                  EpiStore<P>{wg0.C, (long)wg0.N, wg0.extra, wg0.N, wg0.vec_c != 0}, arena);
+    const int wq = bid - dg0.end, sl = wq / wg0.tiles, tile = xcd_remap(wq % wg0.tiles, wg0.tiles);
+    const GemmOperand<T> Bop{wg0.Bptr, nullptr, wg0.ldb, wg0.vec_b != 0};
+    if (wg0.S == 1) {
+      gemm_tile<CW>(A, Bop, wg0.M, wg0.N, wg0.K, tile / wg0.tiles_n, tile % wg0.tiles_n, XfEmbraceMask{(uint8_t)wg0.want},
+                    wg0.N, EpiStore<P>{wg0.C, (long)wg0.N, wg0.extra, wg0.N, wg0.vec_c != 0}, arena);
+    } else {   // batch slice sl: partial sums (bias column included) to this slice's slab
+      const int k_begin = sl * wg0.kper, k_end = min(wg0.K, k_begin + wg0.kper);
+      gemm_tile<CW>(A, Bop, wg0.M, wg0.N, k_end, tile / wg0.tiles_n, tile % wg0.tiles_n, XfEmbraceMask{(uint8_t)wg0.want},
+                    wg0.N, EpiStore<P>{wg0.slab + (long)sl * wg0.M * (wg0.N + 1), (long)(wg0.N + 1), nullptr, wg0.N + 1, false},
+                    arena, k_begin);
+    }
   }
+}
+
+// dW_m / db_m from the per-slice slabs of both modalities, slices summed in order (deterministic)
+template <typename P>
+__global__ void embrace_wgrad_reduce_kernel(const P* __restrict__ slab1, int S1, int N1, P* __restrict__ dW1, P* __restrict__ db1,
+                                            const P* __restrict__ slab0, int S0, int N0, P* __restrict__ dW0, P* __restrict__ db0,
+                                            int M) {
+  const long per1 = S1 > 1 ? (long)M * (N1 + 1) : 0, per0 = S0 > 1 ? (long)M * (N0 + 1) : 0;
+  long q = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  const P* slab; P* dW; P* db; int S, N; long per;
+  if (q < per1) { slab = slab1; dW = dW1; db = db1; S = S1; N = N1; per = per1; }
+  else { q -= per1; if (q >= per0) return; slab = slab0; dW = dW0; db = db0; S = S0; N = N0; per = per0; }
+  P a = 0;
+  for (int sl = 0; sl < S; ++sl) a += slab[(long)sl * per + q];
+  const int m = (int)(q / (N + 1)), n = (int)(q % (N + 1));
+  if (n == N) db[m] = a;
+  else dW[(long)m * N + n] = a;
 }
 
 template <typename T>
 static int bwd_dispatch(const void* dE, const uint8_t* code, const void* X0, const void* X1, const void* W0, const void* W1,
-                        void* dX0, void* dX1, void* dW0, void* db0, void* dW1, void* db1, int B, int d0, int d1, int c,
-                        hipStream_t s) {
+                        void* dX0, void* dX1, void* dW0, void* db0, void* dW1, void* db1, void* ws, int64_t ws_bytes, int B, int d0,
+                        int d1, int c, hipStream_t s) {
   using P = typename AccOf<T>::type;
   using CD = typename BwdCfg<T>::D;
   using CW = typename BwdCfg<T>::W;
   constexpr int VEC = Elem<T>::VEC;
   const int vec_e = (c % VEC == 0) && aligned16(dE) && ((reinterpret_cast<uintptr_t>(code) & 7u) == 0);
   int n = 0;
+  int64_t ws_used = 0;
   auto dgrad = [&](const void* W, void* dX, int d, int m) {
     BwdJob<T, T> j{};
     j.Bptr = (const T*)W; j.C = (T*)dX; j.extra = nullptr;
@@ -104,7 +138,22 @@ static int bwd_dispatch(const void* dE, const uint8_t* code, const void* X0, con
     j.Bptr = (const T*)X; j.C = (P*)dW; j.extra = (P*)db;
     j.M = c; j.N = d; j.K = B; j.ldb = d;
     j.tiles_n = cdiv(d + 1, CW::BN);
-    n += cdiv(c, CW::BM) * j.tiles_n;
+    j.tiles = cdiv(c, CW::BM) * j.tiles_n;
+    j.S = 1; j.kper = B; j.slab = nullptr;
+    if (ws != nullptr && j.tiles < 256 && B >= 4 * CW::BK) {   // few output tiles, long batch: slice the batch
+      int S = 512 / j.tiles;
+      if (S > 8) S = 8;
+      if (S > B / (2 * CW::BK)) S = B / (2 * CW::BK);
+      const int64_t per = (int64_t)c * (d + 1) * (int64_t)sizeof(P);
+      if ((int64_t)S * per > ws_bytes - ws_used) S = (int)((ws_bytes - ws_used) / per);
+      if (S > 1) {
+        j.kper = cdiv(cdiv(B, S), CW::BK) * CW::BK;
+        j.S = cdiv(B, j.kper);
+        j.slab = (P*)((char*)ws + ws_used);
+        ws_used += (int64_t)j.S * per;
+      }
+    }
+    n += j.tiles * j.S;
     j.end = n;
     j.want = (m ? EMB_CODE_IDX : 0) | EMB_CODE_ACTIVE;
     j.vec_b = (d % VEC == 0) && aligned16(X);
@@ -123,21 +172,28 @@ static int bwd_dispatch(const void* dE, const uint8_t* code, const void* X0, con
   }
   embrace_bwd_kernel<T><<<n, kThreads, lds, s>>>((const T*)dE, code, c, vec_e, dg1, wg1, dg0, wg0);
   EMB_CHECK_LAUNCH();
+  if (wg1.S > 1 || wg0.S > 1) {
+    const long total = (wg1.S > 1 ? (long)c * (d1 + 1) : 0) + (wg0.S > 1 ? (long)c * (d0 + 1) : 0);
+    embrace_wgrad_reduce_kernel<P><<<(int)((total + 255) / 256), 256, 0, s>>>(wg1.slab, wg1.S, d1, (P*)dW1, (P*)db1, wg0.slab, wg0.S, d0,
+                                                                             (P*)dW0, (P*)db0, c);
+    EMB_CHECK_LAUNCH();
+  }
   return EMB_OK;
 }
 
 }  // namespace emb
 
 extern "C" int emb_embrace_bwd(const void* dE, const uint8_t* code, const void* X0, const void* X1, const void* W0,
-                               const void* W1, void* dX0, void* dX1, void* dW0, void* db0, void* dW1, void* db1, int B,
-                               int d0, int d1, int c, int dtype, emb_stream_t stream) {
+                               const void* W1, void* dX0, void* dX1, void* dW0, void* db0, void* dW1, void* db1,
+                               void* workspace, int64_t workspace_bytes, int B, int d0, int d1, int c, int dtype,
+                               emb_stream_t stream) {
   EMB_CHECK_ARG(dE && code && X0 && X1 && W0 && W1 && dW0 && db0 && dW1 && db1, "emb_embrace_bwd: null pointer");
   EMB_CHECK_ARG(B > 0 && d0 > 0 && d1 > 0 && c > 0, "emb_embrace_bwd: bad dims B=%d d0=%d d1=%d c=%d", B, d0, d1, c);
   hipStream_t s = (hipStream_t)stream;
   switch (dtype) {
-    case EMB_F32: return emb::bwd_dispatch<float>(dE, code, X0, X1, W0, W1, dX0, dX1, dW0, db0, dW1, db1, B, d0, d1, c, s);
-    case EMB_BF16: return emb::bwd_dispatch<__bf16>(dE, code, X0, X1, W0, W1, dX0, dX1, dW0, db0, dW1, db1, B, d0, d1, c, s);
-    case EMB_F64: return emb::bwd_dispatch<double>(dE, code, X0, X1, W0, W1, dX0, dX1, dW0, db0, dW1, db1, B, d0, d1, c, s);
+    case EMB_F32: return emb::bwd_dispatch<float>(dE, code, X0, X1, W0, W1, dX0, dX1, dW0, db0, dW1, db1, workspace, workspace_bytes, B, d0, d1, c, s);
+    case EMB_BF16: return emb::bwd_dispatch<__bf16>(dE, code, X0, X1, W0, W1, dX0, dX1, dW0, db0, dW1, db1, workspace, workspace_bytes, B, d0, d1, c, s);
+    case EMB_F64: return emb::bwd_dispatch<double>(dE, code, X0, X1, W0, W1, dX0, dX1, dW0, db0, dW1, db1, workspace, workspace_bytes, B, d0, d1, c, s);
   }
   emb::set_error("emb_embrace_bwd: unsupported dtype %d", dtype);
   return EMB_ERR_DTYPE;

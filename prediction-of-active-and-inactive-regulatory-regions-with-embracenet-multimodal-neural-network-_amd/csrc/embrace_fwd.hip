@@ -6,8 +6,8 @@
 // X1/W1), keeps both accumulator tiles, parks them in LDS and finishes with a row-major cooperative
 // epilogue: idx = (double)cdf0[row] < u[row][col] (u injected, or Philox keyed on the global element
 // index), pre = acc_idx + b_idx[col], E = max(pre, 0), code = idx | (pre > 0) << 1.
-#include "gemm_core.h"
-#include "philox.h"
+#include "embrace_epilogue.h"
+#include "embrace_stream.h"
 
 namespace emb {
 
@@ -47,57 +47,7 @@ __global__ __launch_bounds__(kThreads) void embrace_fwd_kernel(
   reduce_to_slab<Cfg>(acc0, cs0);
   reduce_to_slab<Cfg>(acc1, cs1);
 
-  const uint64_t stream = rng_stream(step_val + (step_dev ? *step_dev : 0), EMB_RNG_SELECT);
-  constexpr int GROUPS = Cfg::BM * Cfg::BN / 4;
-  for (int gidx = threadIdx.x; gidx < GROUPS; gidx += kThreads) {
-    const int r = gidx / (Cfg::BN / 4), cq = (gidx % (Cfg::BN / 4)) * 4;
-    const int row = row0 + r, col = col0 + cq;
-    if (row >= B || col >= c) continue;
-    const double thr = (double)cdf0[row];
-    const long base = (long)row * c + col;
-    const int nval = min(4, c - col);
-    double uu[4];
-    if (u != nullptr) {
-      if (nval == 4 && vec_c) {
-        const f64x2 a = *reinterpret_cast<const f64x2*>(u + base);
-        const f64x2 b = *reinterpret_cast<const f64x2*>(u + base + 2);
-        uu[0] = a[0]; uu[1] = a[1]; uu[2] = b[0]; uu[3] = b[1];
-      } else {
-#pragma unroll
-        for (int j = 0; j < 4; ++j) uu[j] = j < nval ? u[base + j] : 0.0;
-      }
-    } else {
-#pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        const Philox4 ph = philox4x32_10(seed, stream, (uint64_t)(grow0 + row) * (uint64_t)c + (uint64_t)(col + j));
-        uu[j] = uniform53(ph.x, ph.y);
-      }
-    }
-    T ev[4];
-    uint8_t cv[4];
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const bool sel1 = thr < uu[j];   // first slot with cdf >= u (ATen binary search, M = 2)
-      const int cc = min(col + j, c - 1);
-      const Acc pre = sel1 ? cs1[r * Cfg::CS + cq + j] + b1[cc] : cs0[r * Cfg::CS + cq + j] + b0[cc];
-      const bool act = pre > (Acc)0;
-      ev[j] = (T)(act ? pre : (Acc)0);
-      cv[j] = (uint8_t)((sel1 ? EMB_CODE_IDX : 0) | (act ? EMB_CODE_ACTIVE : 0));
-    }
-    if (nval == 4 && vec_c) {
-      typedef T TV4 __attribute__((ext_vector_type(4)));
-      TV4 o = {ev[0], ev[1], ev[2], ev[3]};
-      *reinterpret_cast<TV4*>(E + base) = o;
-      *reinterpret_cast<uint32_t*>(code + base) = (uint32_t)cv[0] | ((uint32_t)cv[1] << 8) | ((uint32_t)cv[2] << 16) | ((uint32_t)cv[3] << 24);
-    } else {
-#pragma unroll
-      for (int j = 0; j < 4; ++j)
-        if (j < nval) {
-          E[base + j] = ev[j];
-          code[base + j] = cv[j];
-        }
-    }
-  }
+  embrace_epilogue<Cfg>(cs0, cs1, b0, b1, cdf0, u, seed, step_val, step_dev, grow0, E, code, B, c, row0, col0, vec_c);
 }
 
 // EmbraceNetMultimodal.py:63-76, :178-184 and the cdf torch.multinomial builds from the row.
@@ -186,6 +136,10 @@ template <typename T> static int fwd_dispatch(const void* X0, const void* X1, co
                                               uint64_t step_val, const uint64_t* step_dev, int64_t row0, void* E,
                                               uint8_t* code, int B, int d0, int d1, int c, hipStream_t s) {
   const long tiles_L = (long)cdiv(B, 64) * cdiv(c, 64);
+  if (tiles_L < 192) {   // small B*c, long K: operands streamed straight into MFMA fragments, K split over the 4 waves
+    const int rc = launch_embrace_fwd_stream<T>(X0, X1, W0, b0, W1, b1, cdf0, u, seed, step_val, step_dev, row0, E, code, B, d0, d1, c, s);
+    if (rc != 1) return rc;
+  }
   if (tiles_L >= 192)
     return launch_fwd<typename FwdCfg<T>::L>(X0, X1, W0, b0, W1, b1, cdf0, u, seed, step_val, step_dev, row0, E, code, B, d0, d1, c, s);
   return launch_fwd<typename FwdCfg<T>::S>(X0, X1, W0, b0, W1, b1, cdf0, u, seed, step_val, step_dev, row0, E, code, B, d0, d1, c, s);

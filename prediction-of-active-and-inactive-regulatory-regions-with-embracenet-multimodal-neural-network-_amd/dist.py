@@ -88,6 +88,36 @@ class GradBucket:
             off += g.numel()
 
 
+class FlatGrads:
+    """All gradients of a parameter list live in ONE flat buffer: `p.grad` is a view into it and the backward
+    kernels write there directly (functional.register_grad_sink), so the data-parallel reduction is a single
+    in-place all-reduce with no flatten / unflatten copies.  `extra` trailing slots ride along in the same
+    collective (bench.py uses them to pre-reduce the next step's class counts).  Do not call
+    zero_grad(set_to_none=True) on these parameters."""
+
+    def __init__(self, params, extra=0):
+        from . import functional as F_
+        self.params = [p for p in params if p.requires_grad]
+        if not self.params:
+            raise ValueError("no trainable parameters")
+        dt, dev = self.params[0].dtype, self.params[0].device
+        sizes = [(p.numel() + 3) // 4 * 4 for p in self.params]        # keep every view 16-byte aligned
+        self.flat = torch.zeros(sum(sizes) + extra, dtype=dt, device=dev)
+        off = 0
+        for p, n in zip(self.params, sizes):
+            if p.dtype != dt or p.device != dev:
+                raise TypeError("FlatGrads needs parameters of one dtype on one device")
+            view = self.flat[off:off + p.numel()].view_as(p)
+            p.grad = view
+            F_.register_grad_sink(p, view)
+            off += n
+        self.extra = self.flat[off:off + extra] if extra else None
+
+    def allreduce(self):
+        if world_size() > 1:
+            dist.all_reduce(self.flat, op=dist.ReduceOp.SUM)
+
+
 def barrier():
     if world_size() > 1:
         dist.barrier()

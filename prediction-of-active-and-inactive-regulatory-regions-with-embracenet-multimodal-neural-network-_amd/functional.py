@@ -73,6 +73,33 @@ def shadow_lookup(w):
     return ent[2]
 
 
+# Optional gradient sinks: when a parameter has a registered sink (dist.FlatGrads: a view into one flat
+# buffer that also is its .grad), the backward kernels write the parameter gradient straight into it and
+# autograd is told "no gradient" -- no per-parameter accumulate / copy kernels, and the data-parallel
+# all-reduce runs in place on the flat buffer.  Every parameter is used once per step, so overwrite == accumulate.
+_GRAD_SINKS = {}
+
+
+def register_grad_sink(p, buf):
+    _GRAD_SINKS[id(p)] = (weakref.ref(p), buf)
+
+
+def clear_grad_sinks():
+    _GRAD_SINKS.clear()
+
+
+def grad_sink(p, dtype):
+    ent = _GRAD_SINKS.get(id(p))
+    if ent is None or ent[0]() is not p:
+        return None
+    buf = ent[1]
+    return buf if (buf.dtype == dtype and buf.shape == p.shape and buf.device == p.device) else None
+
+
+def _out(sink, shape, dtype, device):
+    return sink if sink is not None else torch.empty(shape, dtype=dtype, device=device)
+
+
 def select_prep(p, avail, B, rng=None, device_dropout=False, status=None):
     """EmbraceNetMultimodal.py:63-76,178-184 + torch.multinomial's cdf -> cdf0[B] (fp32, device)."""
     _lib.require_cuda(p, avail)
@@ -116,6 +143,7 @@ class _EmbraceFn(torch.autograd.Function):
         ctx.save_for_backward(x0c, x1c, w0c, w1c, code)
         ctx.T = T
         ctx.in_dtypes = (x0.dtype, x1.dtype, w0.dtype, b0.dtype, w1.dtype, b1.dtype)
+        ctx.sinks = tuple(grad_sink(q, P) for q in (w0, b0, w1, b1))
         ctx.mark_non_differentiable(code)
         return E, code
 
@@ -132,17 +160,18 @@ class _EmbraceFn(torch.autograd.Function):
         need0, need1 = ctx.needs_input_grad[0], ctx.needs_input_grad[1]
         dX0 = torch.empty(B, d0, dtype=T, device=dev) if need0 else None
         dX1 = torch.empty(B, d1, dtype=T, device=dev) if need1 else None
-        dW0 = torch.empty(c, d0, dtype=P, device=dev)
-        dW1 = torch.empty(c, d1, dtype=P, device=dev)
-        db0 = torch.empty(c, dtype=P, device=dev)
-        db1 = torch.empty(c, dtype=P, device=dev)
+        sk = ctx.sinks
+        dW0, db0 = _out(sk[0], (c, d0), P, dev), _out(sk[1], (c,), P, dev)
+        dW1, db1 = _out(sk[2], (c, d1), P, dev), _out(sk[3], (c,), P, dev)
+        ws = _workspace(dev, 1 << 24)
         check(_lib.lib().emb_embrace_bwd(ptr(dE), ptr(code), ptr(x0c), ptr(x1c), ptr(w0c), ptr(w1c), ptr(dX0), ptr(dX1),
-                                         ptr(dW0), ptr(db0), ptr(dW1), ptr(db1), B, d0, d1, c, DTYPE_CODE[T], stream()),
-              "emb_embrace_bwd")
+                                         ptr(dW0), ptr(db0), ptr(dW1), ptr(db1), ptr(ws), ws.numel(), B, d0, d1, c,
+                                         DTYPE_CODE[T], stream()), "emb_embrace_bwd")
         t = ctx.in_dtypes
         cast = lambda g, d: None if g is None else (g if g.dtype == d else g.to(d))
-        return (cast(dX0, t[0]), cast(dX1, t[1]), cast(dW0, t[2]), cast(db0, t[3]), cast(dW1, t[4]), cast(db1, t[5]),
-                None, None, None, None)
+        ret = lambda g, d, sink: None if sink is not None else cast(g, d)
+        return (cast(dX0, t[0]), cast(dX1, t[1]), ret(dW0, t[2], sk[0]), ret(db0, t[3], sk[1]), ret(dW1, t[4], sk[2]),
+                ret(db1, t[5], sk[3]), None, None, None, None)
 
 
 def embrace(x0, x1, w0, b0, w1, b1, cdf0, u=None, rng=None, compute_dtype=None):
@@ -169,6 +198,7 @@ class _LinearFn(torch.autograd.Function):
                                         DTYPE_CODE[T], stream()), "emb_linear_fwd")
         ctx.save_for_backward(xc, wc, mask)
         ctx.cfg = (T, bool(relu), float(dropout_p), x.dtype, w.dtype, b.dtype)
+        ctx.sinks = (grad_sink(w, P), grad_sink(b, P))
         return y
 
     @staticmethod
@@ -180,13 +210,14 @@ class _LinearFn(torch.autograd.Function):
         N = wc.shape[0]
         dy = _as(dy, T)
         dx = torch.empty(B, K, dtype=T, device=xc.device) if ctx.needs_input_grad[0] else None
-        dw = torch.empty(N, K, dtype=P, device=xc.device)
-        db = torch.empty(N, dtype=P, device=xc.device)
+        sk = ctx.sinks
+        dw, db = _out(sk[0], (N, K), P, xc.device), _out(sk[1], (N,), P, xc.device)
         ws = _workspace(xc.device, 1 << 22)
         check(_lib.lib().emb_linear_bwd(ptr(dy), ptr(mask), ptr(xc), ptr(wc), ptr(dx), ptr(dw), ptr(db), int(relu),
                                         dropout_p, ptr(ws), ws.numel(), B, K, N, DTYPE_CODE[T], stream()), "emb_linear_bwd")
         cast = lambda g, d: None if g is None else (g if g.dtype == d else g.to(d))
-        return cast(dx, tx), cast(dw, tw), cast(db, tb), None, None, None, None, None
+        return (cast(dx, tx), None if sk[0] is not None else cast(dw, tw), None if sk[1] is not None else cast(db, tb),
+                None, None, None, None, None)
 
 
 def linear(x, w, b, relu=False, dropout_p=0.0, layer_id=0, rng=None, compute_dtype=None):
@@ -312,6 +343,7 @@ class _ConvStackFn(torch.autograd.Function):
             cur, L, cin_pad = out, Lp, Cout
         ctx.save_for_backward(*saved)
         ctx.cfg = (T, int(training), B, shapes)
+        ctx.sinks = tuple(grad_sink(tensors[6 * i + j], P) for i in range(n_layers) for j in range(4))
         return cur.reshape(B, -1)
 
     @staticmethod
@@ -330,15 +362,16 @@ class _ConvStackFn(torch.autograd.Function):
             last = i == len(shapes) - 1
             dy = torch.empty(B, L, Cout, dtype=T, device=dev)
             dx = torch.empty(B, L, cin_pad, dtype=T, device=dev) if i > 0 else None
-            dW = torch.empty(Cout, Cin, k, dtype=P, device=dev)
-            db, dgam, dbeta = (torch.empty(Cout, dtype=P, device=dev) for _ in range(3))
+            sk = ctx.sinks[4 * i:4 * i + 4]
+            dW = _out(sk[0], (Cout, Cin, k), P, dev)
+            db, dgam, dbeta = (_out(sk[j], (Cout,), P, dev) for j in (1, 2, 3))
             nbytes = L_.emb_convblock_workspace_bytes(B, L, cin_pad, Cout, k, code)
             ws = _workspace(dev, nbytes)
             check(L_.emb_convblock_bwd(ptr(g), int(last), ptr(argmax), ptr(y), ptr(stats), ptr(xin),
                                        ptr(wflip) if i > 0 else None, drop_p, training, ptr(dx), ptr(dW), ptr(db), ptr(dgam),
                                        ptr(dbeta), ptr(dy), ptr(ws), ws.numel(), B, L, Cin, cin_pad, Cout, k, code, stream()),
                   "emb_convblock_bwd")
-            grads[6 * i:6 * i + 4] = [dW, db, dgam, dbeta]
+            grads[6 * i:6 * i + 4] = [None if sk[j] is not None else g_ for j, g_ in enumerate((dW, db, dgam, dbeta))]
             g = dx
         return (None, None, None, None, None, *grads)
 
