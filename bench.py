@@ -205,7 +205,7 @@ def main():
     model = training.prepare_model(model, device, wl["dtype"]).set_rng("philox", seed=2024, row0=rank * B)
     opt = optim.Adam(model.parameters(), lr=1e-3, weight_decay=1e-3)
     x1, x2, y = synth_batch(B, Fin, wl["pos"], device, 100 + rank)
-    in_dt = next(model.parameters()).dtype
+    in_dt = model.compute_dtype or next(model.parameters()).dtype   # inputs staged in the compute dtype
     x1, x2 = x1.to(in_dt), x2.to(in_dt)
     counts = torch.zeros(2, dtype=torch.int64, device=device)
     table = ea.metrics.StepTable(1, device)
@@ -223,8 +223,9 @@ def main():
         if flat is None:
             opt.zero_grad(set_to_none=True)
         out = model([x1, x2], is_training=True)
-        loss = F.weighted_ce(out, y, class_counts=counts, global_counts=world > 1, confusion=conf_slot, loss_out=loss_slot)
-        loss.backward()
+        _, dlogits = F.weighted_ce_with_grad(out, y, class_counts=counts, global_counts=world > 1, confusion=conf_slot,
+                                             loss_out=loss_slot)
+        out.backward(dlogits)
 
     def reduce_grads():
         flat.extra.copy_(local_counts)                    # next batch's labels (synthetic: the same batch)

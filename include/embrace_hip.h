@@ -134,6 +134,23 @@ int emb_nadam_step(void* param, const void* grad, void* exp_avg, void* exp_avg_s
                    double weight_decay, double schedule_decay, uint64_t step_val, const uint64_t* step_dev,
                    int dtype, emb_stream_t stream);
 
+/* Small MLP stacks fused into one forward launch and two backward launches (FFNN_pre.py:18-49; the post stack
+ * and the Linear(->2) head of EmbraceNetMultimodal.py:134-154).  L <= 4 layers, Y_l = dropout(relu(Y_{l-1} W_l^T +
+ * b_l)) with per-layer relu flag / dropout_p / RNG layer id.  Pointer and int arrays are HOST arrays of length L
+ * (they travel in the kernel argument); h[l] [B][N_l] T receives every layer's output (h[L-1] is the result),
+ * mask[l] [B][N_l] u8 its mask byte (entry may be NULL for a layer with neither ReLU nor dropout).
+ * emb_mlp_supported() tells whether a stack fits the kernel's LDS budget; otherwise call emb_linear_* per layer.
+ * emb_mlp_bwd: dy [B][N_{L-1}] T -> dx [B][F] T (nullable), dW[l] [N_l][K_l] P, db[l] [N_l] P; workspace holds
+ * ceil(B/32) (ceil(B/16) for EMB_F64) partial sums of all weight gradients, reduced in fixed order. */
+int emb_mlp_supported(int F, const int* N, int L, int dtype);
+int emb_mlp_fwd(const void* x, const void* const* W, const void* const* b, void* const* h, uint8_t* const* mask,
+                const int* N, const int* relu, const float* dropout_p, const int* layer_id, int L, int B, int F,
+                uint64_t seed, uint64_t step_val, const uint64_t* step_dev, int64_t row0, int dtype,
+                emb_stream_t stream);
+int emb_mlp_bwd(const void* x, const void* const* W, const void* const* h, const uint8_t* const* mask, const void* dy,
+                void* dx, void* const* dW, void* const* db, const int* N, const int* relu, const float* dropout_p,
+                int L, int B, int F, void* workspace, int64_t workspace_bytes, int dtype, emb_stream_t stream);
+
 /* Multi-tensor forms: ONE launch updates `ntensors` parameter tensors (<= 40 per launch, chunked inside).
  * The pointer / size arrays are HOST arrays read at call time (they travel in the kernel argument, so a
  * captured call replays with the captured addresses); the tensors they point to are device memory.
@@ -159,7 +176,8 @@ int emb_nadam_step_multi(void* const* params, const void* const* grads, void* co
  *   emb_convblock_workspace_bytes  scratch the two calls below need (caller allocates; contents are transient)
  *   emb_convblock_fwd     y[B][L][Cout] T = conv + bias (kept for backward); stats[4][Cout] P = mean, invstd,
  *                         scale, shift (batch statistics when training != 0, running statistics otherwise;
- *                         running_mean/var updated with `momentum` as nn.BatchNorm1d does);
+ *                         running_mean/var updated with `momentum` as nn.BatchNorm1d does, *num_batches_tracked
+ *                         (nullable, device int64) incremented when training);
  *                         out = dropout(maxpool(relu(bn(y)))) as [B][Lp][Cout] or, out_ncl != 0, [B][Cout][Lp]
  *                         (the flatten order of CNN_pre.py:74); argmax[B][Lp][Cout] u8 (bits 0-3 window
  *                         offset of the maximum, bit 7 dropped).  Dropout mask: RNG kind 16+layer_id.
@@ -174,8 +192,8 @@ int emb_convblock_fwd(const void* x, const void* wpack, const void* bias, const 
                       void* running_mean, void* running_var, int training, double momentum, double eps,
                       float dropout_p, uint64_t seed, uint64_t step_val, const uint64_t* step_dev, int64_t row0,
                       int layer_id, void* y, void* stats, void* out, uint8_t* argmax, int out_ncl, void* workspace,
-                      int64_t workspace_bytes, int B, int L, int cin_pad, int Cout, int k, int dtype,
-                      emb_stream_t stream);
+                      int64_t workspace_bytes, int64_t* num_batches_tracked, int B, int L, int cin_pad, int Cout,
+                      int k, int dtype, emb_stream_t stream);
 int emb_convblock_bwd(const void* dout, int dout_ncl, const uint8_t* argmax, const void* y, const void* stats,
                       const void* x, const void* wflip, float dropout_p, int training, void* dx, void* dW,
                       void* dbias, void* dgamma, void* dbeta, void* dy, void* workspace, int64_t workspace_bytes,

@@ -38,13 +38,16 @@ SIGNATURES = {
     "emb_adam_step": [_vp] * 5 + [_i64, _d, _d, _d, _d, _d, _u64, _vp, _i, _vp],
     "emb_rmsprop_step": [_vp] * 4 + [_i64, _d, _d, _d, _d, _i, _vp],
     "emb_nadam_step": [_vp] * 6 + [_i64, _d, _d, _d, _d, _d, _d, _u64, _vp, _i, _vp],
+    "emb_mlp_supported": [_i, _vp, _i, _i],
+    "emb_mlp_fwd": [_vp] * 9 + [_i, _i, _i, _u64, _u64, _vp, _i64, _i, _vp],
+    "emb_mlp_bwd": [_vp] * 11 + [_i, _i, _i, _vp, _i64, _i, _vp],
     "emb_adam_step_multi": [_vp] * 6 + [_i, _d, _d, _d, _d, _d, _u64, _vp, _i, _vp],
     "emb_rmsprop_step_multi": [_vp] * 5 + [_i, _d, _d, _d, _d, _i, _vp],
     "emb_nadam_step_multi": [_vp] * 7 + [_i, _d, _d, _d, _d, _d, _d, _u64, _vp, _i, _vp],
     "emb_convblock_workspace_bytes": [_i, _i, _i, _i, _i, _i],
     "emb_ncl_to_nlc": [_vp, _i, _vp, _i, _i, _i, _i, _i, _vp],
     "emb_conv_pack_weight": [_vp, _vp, _vp, _i, _i, _i, _i, _i, _vp],
-    "emb_convblock_fwd": [_vp] * 7 + [_i, _d, _d, _f, _u64, _u64, _vp, _i64, _i, _vp, _vp, _vp, _vp, _i, _vp, _i64,
+    "emb_convblock_fwd": [_vp] * 7 + [_i, _d, _d, _f, _u64, _u64, _vp, _i64, _i, _vp, _vp, _vp, _vp, _i, _vp, _i64, _vp,
                                      _i, _i, _i, _i, _i, _i, _vp],
     "emb_convblock_bwd": [_vp, _i, _vp, _vp, _vp, _vp, _vp, _f, _i] + [_vp] * 7 + [_i64, _i, _i, _i, _i, _i, _i, _i, _vp],
     "emb_cast": [_vp, _i, _vp, _i, _i64, _vp],

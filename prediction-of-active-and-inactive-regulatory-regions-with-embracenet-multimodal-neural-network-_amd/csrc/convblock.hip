@@ -146,12 +146,14 @@ template <typename P>
 __global__ __launch_bounds__(256) void bn_finalize_kernel(const P* __restrict__ partial, int tiles_m, int C, double count,
                                                           const P* __restrict__ gamma, const P* __restrict__ beta,
                                                           P* __restrict__ running_mean, P* __restrict__ running_var,
-                                                          int training, double momentum, double eps, P* __restrict__ stats) {
+                                                          int training, double momentum, double eps, P* __restrict__ stats,
+                                                          long long* __restrict__ num_batches_tracked) {
   __shared__ double sa[256], sb[256];
   const int c = blockIdx.x, tid = threadIdx.x;
   double mean, var;
   if (training) {
     double a = 0, b = 0;
+#pragma unroll 4
     for (int t = tid; t < tiles_m; t += 256) {
       a += (double)partial[((long)t * 2 + 0) * C + c];
       b += (double)partial[((long)t * 2 + 1) * C + c];
@@ -184,6 +186,7 @@ __global__ __launch_bounds__(256) void bn_finalize_kernel(const P* __restrict__ 
       const double unbiased = count > 1 ? var * count / (count - 1.0) : var;
       running_mean[c] = (P)((1.0 - momentum) * (double)running_mean[c] + momentum * mean);
       running_var[c] = (P)((1.0 - momentum) * (double)running_var[c] + momentum * unbiased);
+      if (c == 0 && num_batches_tracked != nullptr) *num_batches_tracked += 1;   // nn.BatchNorm1d bookkeeping
     }
   }
 }
@@ -371,6 +374,7 @@ __global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(const P* __restric
   __shared__ double sa[256], sb[256];
   const int c = blockIdx.x, tid = threadIdx.x;
   double a = 0, b = 0;
+#pragma unroll 4
   for (int t = tid; t < nblk; t += 256) {
     a += (double)bpart[((long)t * 2 + 0) * C + c];
     b += (double)bpart[((long)t * 2 + 1) * C + c];
@@ -467,8 +471,10 @@ __global__ __launch_bounds__(256) void conv_wgrad_reduce_kernel(const P* __restr
   const int qi = threadIdx.x & 15, sl = threadIdx.x >> 4;
   const long q = (long)blockIdx.x * 16 + qi;
   P a = 0;
-  if (q < per)
+  if (q < per) {
+#pragma unroll 8
     for (int s = sl; s < S; s += 16) a += slab[(long)s * per + q];
+  }
   red[sl][qi] = a;
   __syncthreads();
   if (sl == 0 && q < per) {
@@ -557,7 +563,7 @@ template <typename T>
 static int convblock_fwd(const void* x, const void* wpack, const void* bias, const void* gamma, const void* beta, void* rmean,
                          void* rvar, int training, double momentum, double eps, float drop_p, uint64_t seed, uint64_t step_val,
                          const uint64_t* step_dev, int64_t row0, int layer_id, void* y, void* stats, void* out, uint8_t* argmax,
-                         int out_ncl, void* ws, int64_t ws_bytes, int B, int L, int cin_pad, int Cout, int k, hipStream_t s) {
+                         int out_ncl, void* ws, int64_t ws_bytes, void* nbt, int B, int L, int cin_pad, int Cout, int k, hipStream_t s) {
   using P = typename AccOf<T>::type;
   constexpr int VEC = Elem<T>::VEC;
   const ConvWs w = conv_workspace<T>(B, L, cin_pad, Cout, k);
@@ -574,7 +580,7 @@ static int convblock_fwd(const void* x, const void* wpack, const void* bias, con
   }
   if (rc != EMB_OK) return rc;
   bn_finalize_kernel<P><<<Cout, 256, 0, s>>>((const P*)ws, tiles_m, Cout, (double)R, (const P*)gamma, (const P*)beta, (P*)rmean,
-                                           (P*)rvar, training, momentum, eps, (P*)stats);
+                                           (P*)rvar, training, momentum, eps, (P*)stats, (long long*)nbt);
   EMB_CHECK_LAUNCH();
   const long total = (long)B * Lp * (Cout / VEC);
   const int grid = (int)((total + 255) / 256);
@@ -714,17 +720,17 @@ extern "C" int emb_convblock_fwd(const void* x, const void* wpack, const void* b
                                  void* running_mean, void* running_var, int training, double momentum, double eps,
                                  float dropout_p, uint64_t seed, uint64_t step_val, const uint64_t* step_dev, int64_t row0,
                                  int layer_id, void* y, void* stats, void* out, uint8_t* argmax, int out_ncl, void* workspace,
-                                 int64_t workspace_bytes, int B, int L, int cin_pad, int Cout, int k, int dtype,
-                                 emb_stream_t stream) {
+                                 int64_t workspace_bytes, int64_t* num_batches_tracked, int B, int L, int cin_pad, int Cout, int k,
+                                 int dtype, emb_stream_t stream) {
   EMB_CHECK_ARG(x && wpack && bias && gamma && beta && running_mean && running_var && y && stats && out && argmax && workspace,
                 "emb_convblock_fwd: null pointer");
   EMB_CHECK_ARG(B > 0 && L > 0 && cin_pad > 0 && Cout > 0 && k > 0 && (k & 1), "emb_convblock_fwd: bad dims");
   EMB_CHECK_ARG(dropout_p >= 0.f && dropout_p < 1.f, "emb_convblock_fwd: dropout_p must be in [0,1)");
   hipStream_t s = (hipStream_t)stream;
   switch (dtype) {
-    case EMB_F32: return convblock_fwd<float>(x, wpack, bias, gamma, beta, running_mean, running_var, training, momentum, eps, dropout_p, seed, step_val, step_dev, row0, layer_id, y, stats, out, argmax, out_ncl, workspace, workspace_bytes, B, L, cin_pad, Cout, k, s);
-    case EMB_BF16: return convblock_fwd<__bf16>(x, wpack, bias, gamma, beta, running_mean, running_var, training, momentum, eps, dropout_p, seed, step_val, step_dev, row0, layer_id, y, stats, out, argmax, out_ncl, workspace, workspace_bytes, B, L, cin_pad, Cout, k, s);
-    case EMB_F64: return convblock_fwd<double>(x, wpack, bias, gamma, beta, running_mean, running_var, training, momentum, eps, dropout_p, seed, step_val, step_dev, row0, layer_id, y, stats, out, argmax, out_ncl, workspace, workspace_bytes, B, L, cin_pad, Cout, k, s);
+    case EMB_F32: return convblock_fwd<float>(x, wpack, bias, gamma, beta, running_mean, running_var, training, momentum, eps, dropout_p, seed, step_val, step_dev, row0, layer_id, y, stats, out, argmax, out_ncl, workspace, workspace_bytes, num_batches_tracked, B, L, cin_pad, Cout, k, s);
+    case EMB_BF16: return convblock_fwd<__bf16>(x, wpack, bias, gamma, beta, running_mean, running_var, training, momentum, eps, dropout_p, seed, step_val, step_dev, row0, layer_id, y, stats, out, argmax, out_ncl, workspace, workspace_bytes, num_batches_tracked, B, L, cin_pad, Cout, k, s);
+    case EMB_F64: return convblock_fwd<double>(x, wpack, bias, gamma, beta, running_mean, running_var, training, momentum, eps, dropout_p, seed, step_val, step_dev, row0, layer_id, y, stats, out, argmax, out_ncl, workspace, workspace_bytes, num_batches_tracked, B, L, cin_pad, Cout, k, s);
   }
   set_error("emb_convblock_fwd: unsupported dtype %d", dtype);
   return EMB_ERR_DTYPE;

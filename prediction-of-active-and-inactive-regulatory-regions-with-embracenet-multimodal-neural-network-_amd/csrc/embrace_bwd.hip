@@ -104,6 +104,7 @@ __global__ void embrace_wgrad_reduce_kernel(const P* __restrict__ slab1, int S1,
   if (q < per1) { slab = slab1; dW = dW1; db = db1; S = S1; N = N1; per = per1; }
   else { q -= per1; if (q >= per0) return; slab = slab0; dW = dW0; db = db0; S = S0; N = N0; per = per0; }
   P a = 0;
+#pragma unroll 8
   for (int sl = 0; sl < S; ++sl) a += slab[(long)sl * per + q];
   const int m = (int)(q / (N + 1)), n = (int)(q % (N + 1));
   if (n == N) db[m] = a;

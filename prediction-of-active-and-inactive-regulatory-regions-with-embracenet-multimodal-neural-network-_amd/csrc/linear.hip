@@ -103,6 +103,7 @@ __global__ void linear_wgrad_reduce_kernel(const P* __restrict__ slab, int S, in
   const long q = (long)blockIdx.x * blockDim.x + threadIdx.x;
   if (q >= per) return;
   P acc = 0;
+#pragma unroll 8
   for (int s = 0; s < S; ++s) acc += slab[(long)s * per + q];
   const int n = (int)(q / (K + 1)), k = (int)(q % (K + 1));
   if (k == K) db[n] = acc;

@@ -53,7 +53,7 @@ class _RngMixin:
 
     def __getstate__(self):
         st = self.__dict__.copy()
-        for k in ("_step_dev", "generator", "last_code", "last_status", "_sel_dev", "_sel_key"):
+        for k in ("_step_dev", "generator", "last_code", "last_status", "_sel_dev", "_sel_key", "_status"):
             if k in st:
                 st[k] = None
         return st
@@ -92,13 +92,16 @@ class EmbraceNet(nn.Module, _RngMixin):
         if p.dim() == 2 and p.shape[0] not in (1, B):
             raise ValueError("selection_probabilities must be [B, M] or [M]")
         avail = None if availabilities is None else availabilities.to(device=dev, dtype=torch.float32)
-        cdf0, status = F_.select_prep(p, avail, B, rng=rng, device_dropout=_device_dropout)
+        if getattr(self, "_status", None) is None or self._status.device != dev:
+            self._status = torch.zeros(1, dtype=torch.int32, device=dev)       # sticky bits, cleared when read
+        cdf0, status = F_.select_prep(p, avail, B, rng=rng, device_dropout=_device_dropout, status=self._status)
 
         u = None
         if self.rng_mode == "host":                               # replay of torch.multinomial's draws (:84)
             u = torch.rand(B * c, dtype=torch.float64, generator=self.generator).view(B, c).to(dev, non_blocking=True)
         check = self.check_distribution if self.check_distribution is not None else (self.rng_mode == "host")
         if check and int(status.item()) & STATUS_INVALID_DISTRIBUTION:
+            status.zero_()
             raise RuntimeError("invalid multinomial distribution (encountering probability entry < 0)")
         self.last_status = status
 
@@ -167,17 +170,17 @@ class EmbraceNetMultimodal(nn.Module, _RngMixin):
     # -- forward ------------------------------------------------------------------------------------
     def _post_forward(self, y, rng, T):
         mods = list(self.post)
-        i, layer_id = 0, 0
+        i, layer_id, layers = 0, 0, []
         while i < len(mods):
             lin = mods[i]
             relu = i + 1 < len(mods) and isinstance(mods[i + 1], nn.ReLU)
             p = 0.0
             if relu and i + 2 < len(mods) and isinstance(mods[i + 2], nn.Dropout):
                 p = float(mods[i + 2].p) if self.training else 0.0
-            y = F_.linear(y, lin.weight, lin.bias, relu=relu, dropout_p=p, layer_id=layer_id, rng=rng, compute_dtype=T)
+            layers.append((lin.weight, lin.bias, relu, p, layer_id))
             i += 3 if relu else 1
             layer_id += 1
-        return y
+        return F_.mlp(y, layers, rng=rng, compute_dtype=T)
 
     def forward(self, x, availabilities=None, selection_probabilities=None, is_training=False,
                 embracenet_dropout=True):

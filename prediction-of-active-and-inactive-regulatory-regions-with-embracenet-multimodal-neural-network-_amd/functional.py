@@ -225,6 +225,94 @@ def linear(x, w, b, relu=False, dropout_p=0.0, layer_id=0, rng=None, compute_dty
     return _LinearFn.apply(x, w, b, relu, dropout_p, layer_id, rng or RngState(), compute_dtype or x.dtype)
 
 
+import ctypes as _ct
+
+
+def _parr(tensors):
+    arr = (_ct.c_void_p * len(tensors))()
+    for i, t in enumerate(tensors):
+        arr[i] = None if t is None else t.data_ptr()
+    return arr
+
+
+class _MlpFn(torch.autograd.Function):
+    """Whole Linear(+ReLU+Dropout) stack in one forward / two backward launches (csrc/mlp.hip).
+    args: x, rng, T, meta (tuple of (relu, drop_p, layer_id) per layer), then W_0, b_0, W_1, b_1, ..."""
+
+    @staticmethod
+    def forward(ctx, x, rng, T, meta, *params):
+        _lib.require_cuda(x)
+        P = PARAM_DTYPE[T]
+        L_ = len(meta)
+        B, Fin = x.shape
+        dev = x.device
+        xc = _as(x, T)
+        Ws = [weight_as(params[2 * l], T) for l in range(L_)]
+        bs = [_as(params[2 * l + 1].detach(), P) for l in range(L_)]
+        Ns = [w.shape[0] for w in Ws]
+        hs = [torch.empty(B, n, dtype=T, device=dev) for n in Ns]
+        masks = [torch.empty(B, n, dtype=torch.uint8, device=dev) if (m[0] or m[1] > 0) else None for n, m in zip(Ns, meta)]
+        iN = (_ct.c_int * L_)(*Ns)
+        irelu = (_ct.c_int * L_)(*[int(bool(m[0])) for m in meta])
+        fdrop = (_ct.c_float * L_)(*[float(m[1]) for m in meta])
+        ilid = (_ct.c_int * L_)(*[int(m[2]) for m in meta])
+        check(_lib.lib().emb_mlp_fwd(ptr(xc), _parr(Ws), _parr(bs), _parr(hs), _parr(masks), iN, irelu, fdrop, ilid, L_, B, Fin,
+                                     rng.seed, rng.step_val, ptr(rng.step_dev), rng.row0, DTYPE_CODE[T], stream()), "emb_mlp_fwd")
+        ctx.save_for_backward(xc, *Ws, *hs, *[m if m is not None else hs[0] for m in masks])
+        ctx.cfg = (T, L_, Ns, [bool(m[0]) for m in meta], [float(m[1]) for m in meta], [m is not None for m in masks],
+                   x.dtype, [params[i].dtype for i in range(2 * L_)])
+        ctx.sinks = tuple(grad_sink(q, P) for q in params)
+        return hs[-1]
+
+    @staticmethod
+    def backward(ctx, dy):
+        T, L_, Ns, relus, drops, has_mask, xdt, pdts = ctx.cfg
+        P = PARAM_DTYPE[T]
+        sv = ctx.saved_tensors
+        xc, Ws, hs, mk = sv[0], sv[1:1 + L_], sv[1 + L_:1 + 2 * L_], sv[1 + 2 * L_:1 + 3 * L_]
+        masks = [m if ok else None for m, ok in zip(mk, has_mask)]
+        B, Fin = xc.shape
+        dev = xc.device
+        dy = _as(dy, T)
+        dx = torch.empty(B, Fin, dtype=T, device=dev) if ctx.needs_input_grad[0] else None
+        Ks = [Fin] + list(Ns[:-1])
+        sk = ctx.sinks
+        dWs = [_out(sk[2 * l], (Ns[l], Ks[l]), P, dev) for l in range(L_)]
+        dbs = [_out(sk[2 * l + 1], (Ns[l],), P, dev) for l in range(L_)]
+        total = sum(n * (k + 1) for n, k in zip(Ns, Ks))
+        rb = 16 if T == torch.float64 else 32
+        need = ((B + rb - 1) // rb) * total * torch.empty(0, dtype=P).element_size()
+        ws = _workspace(dev, max(need, 1 << 22))
+        iN = (_ct.c_int * L_)(*Ns)
+        irelu = (_ct.c_int * L_)(*[int(r) for r in relus])
+        fdrop = (_ct.c_float * L_)(*drops)
+        check(_lib.lib().emb_mlp_bwd(ptr(xc), _parr(Ws), _parr(hs), _parr(masks), ptr(dy), ptr(dx), _parr(dWs), _parr(dbs), iN, irelu,
+                                     fdrop, L_, B, Fin, ptr(ws), ws.numel(), DTYPE_CODE[T], stream()), "emb_mlp_bwd")
+        cast = lambda g, d: None if g is None else (g if g.dtype == d else g.to(d))
+        grads = []
+        for l in range(L_):
+            grads += [None if sk[2 * l] is not None else cast(dWs[l], pdts[2 * l]),
+                      None if sk[2 * l + 1] is not None else cast(dbs[l], pdts[2 * l + 1])]
+        return (cast(dx, xdt), None, None, None, *grads)
+
+
+def mlp(x, layers, rng=None, compute_dtype=None):
+    """layers: list of (weight, bias, relu, dropout_p, layer_id).  One fused launch when the stack fits the kernel
+    (emb_mlp_supported), otherwise one tiled GEMM launch per layer."""
+    T = compute_dtype or x.dtype
+    rng = rng or RngState()
+    Ns = [w.shape[0] for w, *_ in layers]
+    ok = x.is_cuda and 1 <= len(layers) <= 4 and _lib.lib().emb_mlp_supported(
+        x.shape[1], (_ct.c_int * len(Ns))(*Ns), len(Ns), DTYPE_CODE[T])
+    if not ok:
+        for w, b, relu, p, lid in layers:
+            x = linear(x, w, b, relu=relu, dropout_p=p, layer_id=lid, rng=rng, compute_dtype=T)
+        return x
+    meta = tuple((bool(relu), float(p), int(lid)) for _, _, relu, p, lid in layers)
+    params = [t for w, b, *_ in layers for t in (w, b)]
+    return _MlpFn.apply(x, rng, T, meta, *params)
+
+
 class _WeightedCEFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, logits, target, class_counts, global_counts, confusion, loss_out):
@@ -257,6 +345,24 @@ def weighted_ce(logits, target, class_counts=None, global_counts=False, confusio
     if class_counts is None:
         class_counts = torch.empty(2, dtype=torch.int64, device=logits.device)
     return _WeightedCEFn.apply(logits, target, class_counts, global_counts, confusion, loss_out)
+
+
+def weighted_ce_with_grad(logits, target, class_counts=None, global_counts=False, confusion=None, loss_out=None):
+    """Same kernel as `weighted_ce`, returning (loss [fp32 scalar, detached], dlogits) so that a trainer can call
+    ``logits.backward(dlogits)`` directly: the loss is the root of the graph and its own gradient is 1."""
+    _lib.require_cuda(logits, target)
+    z = logits.detach()
+    z = z if z.is_contiguous() else z.contiguous()
+    tgt = _as(target.reshape(-1), torch.int64)
+    if z.shape[1] != 2:
+        raise NotImplementedError("weighted CE kernel implements the reference's 2-class task")
+    if class_counts is None:
+        class_counts = torch.empty(2, dtype=torch.int64, device=z.device)
+    loss = loss_out if loss_out is not None else torch.empty(1, dtype=torch.float32, device=z.device)
+    dz = torch.empty_like(z)
+    check(_lib.lib().emb_weighted_ce(ptr(z), ptr(tgt), ptr(class_counts), int(bool(global_counts)), ptr(loss), ptr(dz),
+                                     ptr(confusion), z.shape[0], DTYPE_CODE[z.dtype], stream()), "emb_weighted_ce")
+    return loss.view(()), dz
 
 
 def count_labels(target, out=None):
@@ -317,6 +423,7 @@ class _ConvStackFn(torch.autograd.Function):
         n_layers = len(meta)
         for i, m in enumerate(meta):
             w, b, g, beta, rmean, rvar = tensors[6 * i:6 * i + 6]
+            nbt = m.get("num_batches_tracked")
             for t in (w, b, g, beta, rmean, rvar):
                 if t.dtype != P:
                     raise TypeError(f"conv stack parameters must be {P} for compute dtype {T}")
@@ -336,8 +443,8 @@ class _ConvStackFn(torch.autograd.Function):
             check(L_.emb_convblock_fwd(ptr(cur), ptr(wpack), ptr(b.detach()), ptr(g.detach()), ptr(beta.detach()), ptr(rmean),
                                        ptr(rvar), int(training), float(m["momentum"]), float(m["eps"]), float(m["drop_p"]),
                                        rng.seed, rng.step_val, ptr(rng.step_dev), rng.row0, int(m["layer_id"]), ptr(y),
-                                       ptr(stats), ptr(out), ptr(argmax), int(last), ptr(ws), ws.numel(), B, L, cin_pad, Cout,
-                                       k, code, stream()), "emb_convblock_fwd")
+                                       ptr(stats), ptr(out), ptr(argmax), int(last), ptr(ws), ws.numel(), ptr(nbt), B, L,
+                                       cin_pad, Cout, k, code, stream()), "emb_convblock_fwd")
             saved += [cur, y, stats, argmax, wflip if wflip is not None else stats]
             shapes.append((L, Cin, cin_pad, Cout, k, float(m["drop_p"])))
             cur, L, cin_pad = out, Lp, Cout
@@ -383,6 +490,7 @@ def conv_stack(x, layers, training, rng=None, compute_dtype=None):
     for ly in layers:
         conv, bn = ly["conv"], ly["bn"]
         meta.append(dict(k=conv.kernel_size[0], drop_p=ly["drop_p"] if training else 0.0,
-                         momentum=0.1 if bn.momentum is None else bn.momentum, eps=bn.eps, layer_id=ly["layer_id"]))
+                         momentum=0.1 if bn.momentum is None else bn.momentum, eps=bn.eps, layer_id=ly["layer_id"],
+                         num_batches_tracked=bn.num_batches_tracked if (training and bn.track_running_stats) else None))
         tensors += [conv.weight, conv.bias, bn.weight, bn.bias, bn.running_mean, bn.running_var]
     return _ConvStackFn.apply(x, bool(training), rng or RngState(), T, tuple(meta), *tensors)

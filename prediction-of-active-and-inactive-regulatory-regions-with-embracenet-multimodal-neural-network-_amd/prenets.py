@@ -47,11 +47,9 @@ class FFNN_pre(nn.Module):
             return self.model(x)
         T = self.compute_dtype or self.model[0].weight.dtype
         mods = list(self.model)
-        for i in range(0, len(mods), 3):
-            p = float(mods[i + 2].p) if self.training else 0.0
-            x = F_.linear(x, mods[i].weight, mods[i].bias, relu=True, dropout_p=p, layer_id=_FFNN_LAYER_ID0 + i // 3,
-                          rng=rng, compute_dtype=T)
-        return x
+        layers = [(mods[i].weight, mods[i].bias, True, float(mods[i + 2].p) if self.training else 0.0, _FFNN_LAYER_ID0 + i // 3)
+                  for i in range(0, len(mods), 3)]
+        return F_.mlp(x, layers, rng=rng, compute_dtype=T)
 
 
 class CNN_pre(nn.Module):
@@ -84,7 +82,5 @@ class CNN_pre(nn.Module):
         for i in range(0, len(mods), 5):
             conv, bn, drop = mods[i], mods[i + 1], mods[i + 4]
             layers.append(dict(conv=conv, bn=bn, drop_p=float(drop.p), layer_id=_CNN_LAYER_ID0 + i // 5))
-            if self.training and bn.track_running_stats and bn.num_batches_tracked is not None:
-                bn.num_batches_tracked.add_(1)
         T = self.compute_dtype or mods[0].weight.dtype
         return F_.conv_stack(x, layers, self.training, rng=rng, compute_dtype=T)

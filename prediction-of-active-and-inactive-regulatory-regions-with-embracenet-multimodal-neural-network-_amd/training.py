@@ -91,7 +91,7 @@ class StepRunner:
     def _forward_loss(self, x_1, x_2, target, training, table):
         model, dev = self.model, self.device
         x_1, x_2, target, row0 = self._shard(x_1, x_2, target)
-        dt = _input_dtype(model)
+        dt = getattr(model, "compute_dtype", None) or _input_dtype(model)   # cast rides on the host->device copy
         x_1 = x_1.to(dev, dtype=dt, non_blocking=True)
         x_2 = x_2.to(dev, dtype=dt, non_blocking=True)
         tgt = target.to(dev, non_blocking=True).reshape(-1)
@@ -106,21 +106,22 @@ class StepRunner:
         else:
             output = model([x_1, x_2])
         loss_slot, count_slot = table.slot()
-        loss = F_.weighted_ce(output, tgt, class_counts=self.counts, global_counts=global_counts,
-                              confusion=count_slot, loss_out=loss_slot)
-        return output, loss
+        loss, dlogits = F_.weighted_ce_with_grad(output, tgt, class_counts=self.counts, global_counts=global_counts,
+                                                 confusion=count_slot, loss_out=loss_slot)
+        return output, loss, dlogits
 
     def train_step(self, x_1, x_2, target, table):
         self.optimizer.zero_grad()
-        output, loss = self._forward_loss(x_1, x_2, target, True, table)
-        loss.backward()
+        output, loss, dlogits = self._forward_loss(x_1, x_2, target, True, table)
+        output.backward(dlogits)        # the loss is the root of the graph: d loss / d logits comes from the loss kernel
         self.bucket.allreduce()
         self.optimizer.step()
         return output, loss
 
     def eval_step(self, x_1, x_2, target, table):
         with torch.no_grad():
-            return self._forward_loss(x_1, x_2, target, False, table)
+            output, loss, _ = self._forward_loss(x_1, x_2, target, False, table)
+        return output, loss
 
 
 def _epoch_scores(table, n_batches_for_mean):
