@@ -143,6 +143,8 @@ int emb_nadam_step(void* param, const void* grad, void* exp_avg, void* exp_avg_s
  * emb_mlp_bwd: dy [B][N_{L-1}] T -> dx [B][F] T (nullable), dW[l] [N_l][K_l] P, db[l] [N_l] P; workspace holds
  * ceil(B/32) (ceil(B/16) for EMB_F64) partial sums of all weight gradients, reduced in fixed order. */
 int emb_mlp_supported(int F, const int* N, int L, int dtype);
+/* bytes of `workspace` emb_mlp_bwd needs for a batch of B rows (0 when the stack is not eligible) */
+int64_t emb_mlp_workspace_bytes(int F, const int* N, int L, int B, int dtype);
 int emb_mlp_fwd(const void* x, const void* const* W, const void* const* b, void* const* h, uint8_t* const* mask,
                 const int* N, const int* relu, const float* dropout_p, const int* layer_id, int L, int B, int F,
                 uint64_t seed, uint64_t step_val, const uint64_t* step_dev, int64_t row0, int dtype,

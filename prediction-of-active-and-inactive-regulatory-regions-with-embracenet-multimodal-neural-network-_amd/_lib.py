@@ -39,6 +39,7 @@ SIGNATURES = {
     "emb_rmsprop_step": [_vp] * 4 + [_i64, _d, _d, _d, _d, _i, _vp],
     "emb_nadam_step": [_vp] * 6 + [_i64, _d, _d, _d, _d, _d, _d, _u64, _vp, _i, _vp],
     "emb_mlp_supported": [_i, _vp, _i, _i],
+    "emb_mlp_workspace_bytes": [_i, _vp, _i, _i, _i],
     "emb_mlp_fwd": [_vp] * 9 + [_i, _i, _i, _u64, _u64, _vp, _i64, _i, _vp],
     "emb_mlp_bwd": [_vp] * 11 + [_i, _i, _i, _vp, _i64, _i, _vp],
     "emb_adam_step_multi": [_vp] * 6 + [_i, _d, _d, _d, _d, _d, _u64, _vp, _i, _vp],
@@ -80,7 +81,8 @@ def lib():
             fn = getattr(L, name)
             fn.argtypes = argtypes
             fn.restype = {"emb_last_error": ctypes.c_char_p,
-                          "emb_convblock_workspace_bytes": ctypes.c_int64}.get(name, ctypes.c_int)
+                          "emb_convblock_workspace_bytes": ctypes.c_int64,
+                          "emb_mlp_workspace_bytes": ctypes.c_int64}.get(name, ctypes.c_int)
         if L.emb_abi_version() != 1:
             raise RuntimeError("libembrace_hip.so ABI version mismatch")
         _lib = L

@@ -279,11 +279,9 @@ class _MlpFn(torch.autograd.Function):
         sk = ctx.sinks
         dWs = [_out(sk[2 * l], (Ns[l], Ks[l]), P, dev) for l in range(L_)]
         dbs = [_out(sk[2 * l + 1], (Ns[l],), P, dev) for l in range(L_)]
-        total = sum(n * (k + 1) for n, k in zip(Ns, Ks))
-        rb = 16 if T == torch.float64 else 32
-        need = ((B + rb - 1) // rb) * total * torch.empty(0, dtype=P).element_size()
-        ws = _workspace(dev, max(need, 1 << 22))
         iN = (_ct.c_int * L_)(*Ns)
+        need = _lib.lib().emb_mlp_workspace_bytes(Fin, iN, L_, B, DTYPE_CODE[T])
+        ws = _workspace(dev, max(need, 1 << 22))
         irelu = (_ct.c_int * L_)(*[int(r) for r in relus])
         fdrop = (_ct.c_float * L_)(*drops)
         check(_lib.lib().emb_mlp_bwd(ptr(xc), _parr(Ws), _parr(hs), _parr(masks), ptr(dy), ptr(dx), _parr(dWs), _parr(dbs), iN, irelu,
