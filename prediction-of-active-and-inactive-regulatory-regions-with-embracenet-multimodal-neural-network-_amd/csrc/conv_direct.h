@@ -38,8 +38,9 @@ inline ConvTiling conv_tiling(int B, int L, int pad) {
 }
 
 // forward (FWD: + bias, + per-tile BatchNorm partial sums) or plain (dgrad); N = output channels
-int launch_conv_direct(int dtype, bool fwd, const void* x, const void* w, const void* bias, void* out, void* partial, int B, int L,
-                       int cin, int KK, int N, int pad, hipStream_t s);
+// *partial_rows (nullable) receives the number of [2][N] partial-sum rows the forward wrote
+int launch_conv_direct(int dtype, bool fwd, const void* x, const void* w, const void* bias, void* out, void* partial, int* partial_rows,
+                       int B, int L, int cin, int KK, int N, int pad, hipStream_t s);
 // slab[S][Cout][KK+1] partial weight gradients (+ bias gradient in column KK); returns S through *S_out
 int launch_conv_wgrad_direct(int dtype, const void* dy, const void* x, void* slab, int B, int L, int cin, int KK, int Cout, int pad,
                              int S, hipStream_t s);

@@ -8,6 +8,17 @@ template <> struct DCfg<__bf16> { static constexpr int WCH = 128, XPAD = 8, WPAD
 template <> struct DCfg<float> { static constexpr int WCH = 64, XPAD = 2, WPAD = 2, BNW = 128; };
 template <> struct DCfg<double> { static constexpr int WCH = 32, XPAD = 2, WPAD = 2, BNW = 128; };
 
+#ifdef EMB_CONV_PROF
+__device__ unsigned long long g_conv_prof[64];
+__device__ int g_conv_prof_sel;   // which kernel family records: 0 fwd/dgrad resident, 1 wgrad
+#define CONV_T(fam, i) do { if (blockIdx.x == 0 && threadIdx.x == 0 && g_conv_prof_sel == fam && (i) < 64) g_conv_prof[i] = wall_clock64(); } while (0)
+__device__ int g_conv_dbg;        // experiment switches (bit set = skip that phase)
+#define CONV_DBG(bit) ((g_conv_dbg >> (bit)) & 1)
+#else
+#define CONV_T(fam, i) do {} while (0)
+#define CONV_DBG(bit) 0
+#endif
+
 constexpr int kXExtra = 8;   // zero rows after the last slot (taps of the zero-padded k*cin tail land there)
 
 template <typename T> __device__ __forceinline__ void lds_store_vec(T* dst, const typename Vec16<T>::type& v) {
@@ -21,13 +32,13 @@ template <typename T> __device__ __forceinline__ void lds_store_vec(T* dst, cons
 }
 
 // activation rows of `SB` sequences starting at b0, times [t0 - pad, t0 - pad + slot) each, zero outside [0, L)
-template <typename T>
+template <typename T, int NTHR = kThreads>
 __device__ __forceinline__ void stage_x_tile(const T* __restrict__ x, T* xs, int XS, int xrows, int SB, int slot, int b0, int t0,
-                                             int B, int L, int cin, int pad) {
+                                             int B, int L, int cin, int pad, int first = 0) {
   constexpr int VEC = Elem<T>::VEC;
   using V = typename Vec16<T>::type;
   const int cvn = cin / VEC;
-  for (int i = threadIdx.x; i < xrows * cvn; i += kThreads) {
+  for (int i = first + threadIdx.x; i < xrows * cvn; i += NTHR) {
     const int row = i / cvn, cv = (i - row * cvn) * VEC;
     const int s = row / slot, tt = t0 - pad + (row - s * slot);
     V v;
@@ -44,6 +55,323 @@ __device__ __forceinline__ int tile_xrow(int r, int L, int SB, int slot) {
   const int rr = min(r, SB * L - 1);
   const int s = rr / L;
   return s * slot + (rr - s * L);
+}
+
+// ---- register-staged tiles --------------------------------------------------------------------------------------
+// A thread's share of an activation tile as a tile-independent plan (LDS slot, global offset relative to the
+// tile origin, validity inputs) so the loads of tile i+1 can be issued -- into registers -- before the MFMA loop
+// of tile i and unpacked into LDS after it: one exposed memory round trip per workgroup instead of one per tile.
+constexpr int kXV = 8;   // activation-tile vectors per thread held in registers (the rest is staged directly)
+
+template <typename T> struct XPlan {
+  int lds[kXV];    // LDS element offset
+  int glb[kXV];    // global element offset relative to x + (b0*L + t0)*cin
+  int pk[kXV];     // (sequence slot << 16) | (row in slot);  -1: not this thread's
+  int live;        // slots any thread of the workgroup uses (uniform)
+};
+
+template <typename T, int NTHR = kThreads>
+__device__ __forceinline__ void xplan_init(XPlan<T>& p, int XS, int xrows, int SB, int slot, int L, int cin, int pad) {
+  constexpr int VEC = Elem<T>::VEC;
+  const int cvn = cin / VEC, nxv = xrows * cvn;
+  p.live = min(kXV, (nxv + NTHR - 1) / NTHR);
+#pragma unroll
+  for (int i = 0; i < kXV; ++i) {
+    const int idx = threadIdx.x + i * NTHR;
+    const int row = idx / cvn, cv = (idx - row * cvn) * VEC, s = row / slot, dtp = row - s * slot;
+    p.lds[i] = row * XS + cv;
+    p.glb[i] = (s * L + dtp - pad) * cin + cv;
+    p.pk[i] = idx < nxv ? (((s < SB ? s : 0x7fff) << 16) | dtp) : -1;
+  }
+}
+
+template <typename T>
+__device__ __forceinline__ void xplan_issue(const XPlan<T>& p, typename Vec16<T>::type (&v)[kXV], const T* __restrict__ x, int b0, int t0,
+                                            int B, int L, int cin, int pad) {
+  using V = typename Vec16<T>::type;
+  const T* xb = x + ((long)b0 * L + t0) * cin;
+#pragma unroll
+  for (int i = 0; i < kXV; ++i) {
+    if (i >= p.live) break;
+    V val;
+#pragma unroll
+    for (int e = 0; e < Elem<T>::VEC; ++e) val[e] = (T)0.0f;
+    if (p.pk[i] >= 0) {
+      const int s = p.pk[i] >> 16, tt = t0 - pad + (p.pk[i] & 0xffff);
+      if (b0 + s < B && tt >= 0 && tt < L) val = *reinterpret_cast<const V*>(xb + p.glb[i]);
+    }
+    v[i] = val;
+  }
+}
+
+template <typename T>
+__device__ __forceinline__ void xplan_commit(const XPlan<T>& p, const typename Vec16<T>::type (&v)[kXV], T* xs) {
+#pragma unroll
+  for (int i = 0; i < kXV; ++i)
+    if (i < p.live && p.pk[i] >= 0) lds_store_vec<T>(xs + p.lds[i], v[i]);
+}
+
+// ---- transposed streaming variant -----------------------------------------------------------------------------------
+// out^T = W . im2col(x)^T : the MFMA M dimension carries the output CHANNELS, N the output rows.  With the weight
+// rows dealt to the MFMA row index so that lane-group g owns channels [g*4MT, (g+1)*4MT) of the tile, every lane
+// ends up holding 4*MT CONSECUTIVE channels of one output row: the result leaves the accumulators as 16-byte
+// row-major stores (a wave writes 16 whole rows per instruction pair) -- no LDS transpose, no barrier in the
+// epilogue.  Each wave owns NT*16 rows; the weights sit in registers (k*cin <= 4 MFMA steps: the one-hot layer) or
+// permuted in LDS (one ds_read_b128 per channel tile and k-step, reused by the wave's NT row tiles); the next
+// tile's activations are in flight during the MFMA loop.  BatchNorm partial sums are kept per lane across ALL of
+// the workgroup's tiles and meet once at the end (4 shuffle steps + 2 KiB of LDS): one partial row per workgroup.
+template <typename T> struct AccMap {   // accumulator register r of lane-group g  <->  MFMA row index m
+  __device__ static int g_of(int m) { return sizeof(T) == 8 ? (m & 3) : (m >> 2); }
+  __device__ static int r_of(int m) { return sizeof(T) == 8 ? (m >> 2) : (m & 3); }
+};
+template <typename T, int MT> __device__ __forceinline__ int chan_of(int mt, int m) {
+  return AccMap<T>::g_of(m) * (4 * MT) + mt * 4 + AccMap<T>::r_of(m);
+}
+constexpr int kWRegSteps = 4;   // weight k-steps a wave can keep in registers
+
+__host__ __device__ inline int conv_t_xpitch(int cin, int elem_bytes) {   // conflict-free 16-byte row reads
+  return elem_bytes == 2 ? ((cin % 16 == 0) ? cin + 8 : cin) : cin + 16 / elem_bytes;
+}
+
+// sum over the 16 lanes of a DPP row (every lane of the row receives it); f64 goes through the LDS crossbar
+template <typename A> __device__ __forceinline__ A row16_sum(A v) {
+  if constexpr (sizeof(A) == 4) {
+    int x = __builtin_bit_cast(int, v);
+#define EMB_DPP_ADD(ctrl) v += __builtin_bit_cast(A, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), ctrl, 0xf, 0xf, true))
+    (void)x;
+    EMB_DPP_ADD(0xB1);    // quad_perm [1,0,3,2]
+    EMB_DPP_ADD(0x4E);    // quad_perm [2,3,0,1]
+    EMB_DPP_ADD(0x124);   // row_ror:4
+    EMB_DPP_ADD(0x128);   // row_ror:8
+#undef EMB_DPP_ADD
+    return v;
+  } else {
+#pragma unroll
+    for (int m = 1; m < 16; m <<= 1) v += __shfl_xor(v, m);
+    return v;
+  }
+}
+
+template <typename T, int MT, int NT, int WAVES, bool FWD, bool WREG>
+__global__ __launch_bounds__(WAVES * 64) void conv_t_kernel(const T* __restrict__ x, const T* __restrict__ w,
+                                                          const typename AccOf<T>::type* __restrict__ bias, T* __restrict__ out,
+                                                          typename AccOf<T>::type* __restrict__ partial, int B, int L, int cin, int KK,
+                                                          int N, int pad, int SB, int tiles_t, int slot, int tiles_m, int tpb, int nblk_m) {
+  using Mm = Mma<T>;
+  using Acc = typename Mm::Acc;
+  using V = typename Vec16<T>::type;
+  constexpr int VEC = Elem<T>::VEC, KSTEP = Mm::KSTEP, BN = 16 * MT, BT = WAVES * 16 * NT, CPL = 4 * MT, NTHR = WAVES * 64;   // CPL: channels per lane
+  constexpr bool BF = sizeof(T) == 2;
+  extern __shared__ __attribute__((aligned(16))) char arena[];
+  const int tn = blockIdx.x / nblk_m, bm = blockIdx.x % nblk_m, col0 = tn * BN;
+  const int tm_begin = bm * tpb, tm_end = min(tiles_m, tm_begin + tpb);
+  const int XS = conv_t_xpitch(cin, (int)sizeof(T)), xrows = SB * slot + kXExtra;
+  const int KKp = (KK + KSTEP - 1) / KSTEP * KSTEP, WSR = KKp + DCfg<T>::WPAD, nks = KKp / KSTEP;
+  T* xs = reinterpret_cast<T*>(arena);
+  T* wsr = xs + (((long)xrows * XS + 7) & ~7L);
+  Acc* red = reinterpret_cast<Acc*>(wsr + (WREG ? 0 : (((long)BN * WSR + 7) & ~7L)));
+  const bool multi = L < BT;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, g = lane >> 4, r16 = lane & 15;
+  const int kl = BF ? 8 * g : g;                       // this lane's k offset inside an MFMA k-step
+
+  CONV_T(0, 0);
+  XPlan<T> xp;
+  V xr[kXV];
+  xplan_init<T, NTHR>(xp, XS, xrows, SB, slot, L, cin, pad);
+  CONV_T(0, 1);
+  if (tm_begin < tm_end) xplan_issue<T>(xp, xr, x, (tm_begin / tiles_t) * SB, (tm_begin % tiles_t) * BT, B, L, cin, pad);
+  CONV_T(0, 2);
+
+  typename Mm::Frag wf[WREG ? MT : 1][WREG ? kWRegSteps : 1];
+  if constexpr (WREG) {
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+      for (int ks = 0; ks < kWRegSteps; ++ks) {
+        const int ch = col0 + chan_of<T, MT>(mt, r16), kk = ks * KSTEP + kl;
+        typename Mm::Frag f;
+        if constexpr (BF) {
+#pragma unroll
+          for (int e = 0; e < 8; ++e) f[e] = (T)0.0f;
+        } else {
+          f = (T)0.0f;
+        }
+        if (ch < N && kk < KK) f = *reinterpret_cast<const typename Mm::Frag*>(w + (long)ch * KK + kk);   // KK % 8 == 0 (bf16)
+        wf[mt][ks] = f;
+      }
+  } else {   // LDS row mt*16 + m holds the weights of channel chan_of(mt, m)
+    const int kvn = KKp / VEC;
+    for (int lr = wave; lr < BN; lr += WAVES) {        // one weight row per wave and pass: no index arithmetic
+      const int ch = col0 + chan_of<T, MT>(lr >> 4, lr & 15);
+      const T* wrow = w + (long)min(ch, N - 1) * KK;
+#pragma unroll 2
+      for (int kv = lane; kv < kvn; kv += 64) {
+        V val;
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) val[e] = (T)0.0f;
+        if (ch < N && kv * VEC < KK) val = *reinterpret_cast<const V*>(wrow + kv * VEC);   // KK % VEC == 0
+        lds_store_vec<T>(wsr + lr * WSR + kv * VEC, val);
+      }
+    }
+  }
+
+  int xrow[NT], row_pk[NT];                            // this lane's output rows: LDS row of tap 0; (slot << 16) | time, -1 = none
+#pragma unroll
+  for (int nt = 0; nt < NT; ++nt) {
+    const int row = wave * (NT * 16) + nt * 16 + r16;
+    const int rr = multi ? min(row, SB * L - 1) : row;
+    const int sq = multi ? rr / L : 0;
+    xrow[nt] = multi ? sq * slot + (rr - sq * L) : row;
+    row_pk[nt] = (multi && row >= SB * L) ? -1 : ((sq << 16) | (rr - sq * L));
+  }
+  Acc bv[MT][4], s1[MT][4], s2[MT][4];
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      bv[mt][r] = FWD ? bias[min(col0 + g * CPL + mt * 4 + r, N - 1)] : (Acc)0;
+      s1[mt][r] = 0;
+      s2[mt][r] = 0;
+    }
+  const int tap0 = kl / cin, ci0 = kl - tap0 * cin, xo0 = tap0 * XS + ci0;
+  const bool vec_out = (N % VEC) == 0 && (CPL % VEC) == 0;
+  CONV_T(0, 3);
+
+  for (int tm = tm_begin; tm < tm_end; ++tm) {
+    const int b0 = (tm / tiles_t) * SB, t0 = (tm % tiles_t) * BT;
+    __syncthreads();                                   // previous tile's LDS reads are done
+    CONV_T(0, 4 + (tm - tm_begin) * 5 + 0);
+    xplan_commit<T>(xp, xr, xs);
+    if (xrows * (cin / VEC) > kXV * NTHR) stage_x_tile<T, NTHR>(x, xs, XS, xrows, SB, slot, b0, t0, B, L, cin, pad, kXV * NTHR);
+    __syncthreads();
+    CONV_T(0, 4 + (tm - tm_begin) * 5 + 1);
+    if (tm + 1 < tm_end) xplan_issue<T>(xp, xr, x, ((tm + 1) / tiles_t) * SB, ((tm + 1) % tiles_t) * BT, B, L, cin, pad);
+    CONV_T(0, 4 + (tm - tm_begin) * 5 + 2);
+
+    typename Mm::AccV acc[MT][NT];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) acc[mt][nt][r] = 0;
+    int xo = xo0, ci = ci0;
+    if constexpr (WREG) {
+#pragma unroll
+      for (int ks = 0; ks < kWRegSteps; ++ks) {
+        if (ks < nks) {
+          typename Mm::Frag bf[NT];
+#pragma unroll
+          for (int nt = 0; nt < NT; ++nt) bf[nt] = *reinterpret_cast<const typename Mm::Frag*>(xs + xrow[nt] * XS + xo);
+#pragma unroll
+          for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = Mm::mma(wf[mt][ks], bf[nt], acc[mt][nt]);
+          ci += KSTEP;
+          xo += KSTEP;
+          while (ci >= cin) { ci -= cin; xo += XS - cin; }   // next tap: one LDS row down
+        }
+      }
+    } else {
+      const T* wl = wsr + r16 * WSR + kl;
+#pragma unroll 2
+      for (int ks = 0; ks < nks; ++ks) {
+        typename Mm::Frag af[MT], bf[NT];
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) af[mt] = *reinterpret_cast<const typename Mm::Frag*>(wl + mt * 16 * WSR + ks * KSTEP);
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) bf[nt] = *reinterpret_cast<const typename Mm::Frag*>(xs + xrow[nt] * XS + xo);
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+          for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = Mm::mma(af[mt], bf[nt], acc[mt][nt]);
+        ci += KSTEP;
+        xo += KSTEP;
+        while (ci >= cin) { ci -= cin; xo += XS - cin; }
+      }
+    }
+
+    CONV_T(0, 4 + (tm - tm_begin) * 5 + 3);
+    // ---- epilogue: straight from the accumulators
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+      const int pk = row_pk[nt];
+      if (pk < 0 || b0 + (pk >> 16) >= B || t0 + (pk & 0xffff) >= L) continue;
+      T ov[CPL];
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const Acc v = acc[mt][nt][r] + bv[mt][r];
+          ov[mt * 4 + r] = (T)v;
+          if (FWD) { s1[mt][r] += v; s2[mt][r] += v * v; }
+        }
+      const int col = col0 + g * CPL;
+      T* dst = out + ((long)(b0 + (pk >> 16)) * L + t0 + (pk & 0xffff)) * N + col;
+      if (vec_out && col + CPL <= N) {
+#pragma unroll
+        for (int q = 0; q < CPL / VEC; ++q) {
+          V o;
+#pragma unroll
+          for (int e = 0; e < VEC; ++e) o[e] = ov[q * VEC + e];
+          *reinterpret_cast<V*>(dst + q * VEC) = o;
+        }
+      } else {
+#pragma unroll
+        for (int j = 0; j < CPL; ++j)
+          if (col + j < N) dst[j] = ov[j];
+      }
+    }
+    CONV_T(0, 4 + (tm - tm_begin) * 5 + 4);
+  }
+
+  if (FWD) {   // one partial row per workgroup: lanes of equal channel set meet (16 row lanes), then the four waves
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const Acc a = row16_sum<Acc>(s1[mt][r]), b = row16_sum<Acc>(s2[mt][r]);
+        if (r16 == 0) {
+          red[(wave * 2 + 0) * BN + g * CPL + mt * 4 + r] = a;
+          red[(wave * 2 + 1) * BN + g * CPL + mt * 4 + r] = b;
+        }
+      }
+    __syncthreads();
+    if (threadIdx.x < 2 * BN) {
+      const int c = threadIdx.x % BN, which = threadIdx.x / BN;
+      if (col0 + c < N) {
+        Acc t = 0;
+#pragma unroll
+        for (int wv = 0; wv < WAVES; ++wv) t += red[(wv * 2 + which) * BN + c];
+        partial[((long)bm * 2 + which) * N + col0 + c] = t;
+      }
+    }
+  }
+  CONV_T(0, 60);
+}
+
+template <typename T, int MT, bool WREG> static size_t conv_t_lds(int cin, int KK, int xrows, int waves) {
+  using Acc = typename AccOf<T>::type;
+  constexpr int KSTEP = Mma<T>::KSTEP;
+  const size_t KKp = (size_t)(KK + KSTEP - 1) / KSTEP * KSTEP;
+  const size_t xs = ((size_t)xrows * conv_t_xpitch(cin, (int)sizeof(T)) + 7) & ~(size_t)7;
+  const size_t ws = WREG ? 0 : (((size_t)16 * MT * (KKp + DCfg<T>::WPAD) + 7) & ~(size_t)7);
+  return (((xs + ws) * sizeof(T) + (size_t)waves * 2 * 16 * MT * sizeof(Acc)) + 15) & ~(size_t)15;
+}
+
+inline ConvTiling conv_tiling_bt(int B, int L, int pad, int BT) {
+  ConvTiling t;
+  if (L >= BT) {
+    t.SB = 1;
+    t.tiles_t = (L + BT - 1) / BT;
+    t.slot = BT + 2 * pad;
+  } else {
+    t.SB = BT / L;
+    t.tiles_t = 1;
+    t.slot = L + 2 * pad;
+  }
+  t.tiles_m = ((B + t.SB - 1) / t.SB) * t.tiles_t;
+  return t;
 }
 
 template <typename T, int BN, bool FWD>
@@ -205,11 +533,62 @@ template <typename T, int BN> static size_t conv_direct_lds(int cin, int SB, int
 
 constexpr size_t kMaxDirectLds = 150 * 1024;
 
-template <typename T, int BN, bool FWD>
-static int launch_direct(const void* x, const void* w, const void* bias, void* out, void* partial, int B, int L, int cin, int KK, int N,
-                         int pad, hipStream_t s) {
+
+// transposed streaming kernel; returns 1 when the shapes do not qualify
+template <typename T, int MT, int WAVES, bool FWD, bool WREG>
+static int launch_conv_t_cfg(const void* x, const void* w, const void* bias, void* out, void* partial, int* partial_rows, int B, int L,
+                             int cin, int KK, int N, int pad, hipStream_t s) {
   using Acc = typename AccOf<T>::type;
+  constexpr int NT = 4, BT = WAVES * 16 * NT;
+  const ConvTiling t = conv_tiling_bt(B, L, pad, BT);
+  const int xrows = t.SB * t.slot + kXExtra, tiles_n = cdiv(N, 16 * MT);
+  const size_t lds = conv_t_lds<T, MT, WREG>(cin, KK, xrows, WAVES);
+  if (lds > kMaxDirectLds) return 1;
+  int per_cu = (int)((160 * 1024) / lds);               // workgroups resident per CU: LDS, then ~2 waves per SIMD of registers
+  const int cap = WAVES == 4 ? 2 : 1;
+  per_cu = per_cu < 1 ? 1 : (per_cu > cap ? cap : per_cu);
+  const int target = 256 * per_cu;
+  const int tpb = cdiv(t.tiles_m * tiles_n, target) < 1 ? 1 : cdiv(t.tiles_m * tiles_n, target);
+  const int nblk_m = cdiv(t.tiles_m, tpb);
+  static bool attr = false;
+  if (!attr) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_t_kernel<T, MT, NT, WAVES, FWD, WREG>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                              (int)kMaxDirectLds);
+    attr = true;
+  }
+  conv_t_kernel<T, MT, NT, WAVES, FWD, WREG><<<nblk_m * tiles_n, WAVES * 64, lds, s>>>((const T*)x, (const T*)w, (const Acc*)bias, (T*)out,
+                                                                                  (Acc*)partial, B, L, cin, KK, N, pad, t.SB, t.tiles_t,
+                                                                                  t.slot, t.tiles_m, tpb, nblk_m);
+  EMB_CHECK_LAUNCH();
+  if (partial_rows) *partial_rows = nblk_m;
+  return EMB_OK;
+}
+
+template <typename T, int MT, bool FWD>
+static int launch_conv_t(const void* x, const void* w, const void* bias, void* out, void* partial, int* partial_rows, int B, int L, int cin,
+                         int KK, int N, int pad, hipStream_t s) {
+  constexpr int KSTEP = Mma<T>::KSTEP, VEC = Elem<T>::VEC;
+  if (!aligned16(x) || !aligned16(w) || !aligned16(out) || KK % VEC || cin % VEC || (sizeof(T) == 2 && KK % 8)) return 1;
+  const bool wreg = cdiv(KK, KSTEP) <= kWRegSteps && MT * kWRegSteps * (int)(sizeof(typename Mma<T>::Frag) / 4) <= 64;
+  if (wreg) return launch_conv_t_cfg<T, MT, 4, FWD, true>(x, w, bias, out, partial, partial_rows, B, L, cin, KK, N, pad, s);
+  // weights in LDS: eight waves share them (two per SIMD to cover the LDS latency); four when that does not fit
+  const int rc = launch_conv_t_cfg<T, MT, 8, FWD, false>(x, w, bias, out, partial, partial_rows, B, L, cin, KK, N, pad, s);
+  if (rc != 1) return rc;
+  return launch_conv_t_cfg<T, MT, 4, FWD, false>(x, w, bias, out, partial, partial_rows, B, L, cin, KK, N, pad, s);
+}
+
+template <typename T, int BN, bool FWD>
+static int launch_direct(const void* x, const void* w, const void* bias, void* out, void* partial, int* partial_rows, int B, int L, int cin,
+                         int KK, int N, int pad, hipStream_t s) {
+  using Acc = typename AccOf<T>::type;
+  {
+    const int rc = N <= 16 ? launch_conv_t<T, 1, FWD>(x, w, bias, out, partial, partial_rows, B, L, cin, KK, N, pad, s)
+                 : N <= 32 ? launch_conv_t<T, 2, FWD>(x, w, bias, out, partial, partial_rows, B, L, cin, KK, N, pad, s)
+                           : launch_conv_t<T, 4, FWD>(x, w, bias, out, partial, partial_rows, B, L, cin, KK, N, pad, s);
+    if (rc != 1) return rc;
+  }
   const ConvTiling t = conv_tiling(B, L, pad);
+  const int tiles_n = cdiv(N, BN);
   const size_t lds = conv_direct_lds<T, BN>(cin, t.SB, t.slot);
   if (lds > kMaxDirectLds) return 1;   // caller falls back to the generic GEMM view
   static size_t attr = 0;
@@ -217,27 +596,27 @@ static int launch_direct(const void* x, const void* w, const void* bias, void* o
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_direct_kernel<T, BN, FWD>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kMaxDirectLds);
     attr = kMaxDirectLds;
   }
-  const int tiles_n = cdiv(N, BN);
   conv_direct_kernel<T, BN, FWD><<<t.tiles_m * tiles_n, kThreads, lds, s>>>((const T*)x, (const T*)w, (const Acc*)bias, (T*)out,
                                                                         (Acc*)partial, B, L, cin, KK, N, pad, t.SB, t.tiles_t, t.slot, tiles_n);
   EMB_CHECK_LAUNCH();
+  if (partial_rows) *partial_rows = t.tiles_m;
   return EMB_OK;
 }
 
 template <typename T> static int launch_direct_t(bool fwd, const void* x, const void* w, const void* bias, void* out, void* partial,
-                                                 int B, int L, int cin, int KK, int N, int pad, hipStream_t s) {
-  if (N >= 64) return fwd ? launch_direct<T, 64, true>(x, w, bias, out, partial, B, L, cin, KK, N, pad, s)
-                          : launch_direct<T, 64, false>(x, w, bias, out, partial, B, L, cin, KK, N, pad, s);
-  return fwd ? launch_direct<T, 32, true>(x, w, bias, out, partial, B, L, cin, KK, N, pad, s)
-             : launch_direct<T, 32, false>(x, w, bias, out, partial, B, L, cin, KK, N, pad, s);
+                                                 int* partial_rows, int B, int L, int cin, int KK, int N, int pad, hipStream_t s) {
+  if (N >= 64) return fwd ? launch_direct<T, 64, true>(x, w, bias, out, partial, partial_rows, B, L, cin, KK, N, pad, s)
+                          : launch_direct<T, 64, false>(x, w, bias, out, partial, partial_rows, B, L, cin, KK, N, pad, s);
+  return fwd ? launch_direct<T, 32, true>(x, w, bias, out, partial, partial_rows, B, L, cin, KK, N, pad, s)
+             : launch_direct<T, 32, false>(x, w, bias, out, partial, partial_rows, B, L, cin, KK, N, pad, s);
 }
 
-int launch_conv_direct(int dtype, bool fwd, const void* x, const void* w, const void* bias, void* out, void* partial, int B, int L,
-                       int cin, int KK, int N, int pad, hipStream_t s) {
+int launch_conv_direct(int dtype, bool fwd, const void* x, const void* w, const void* bias, void* out, void* partial, int* partial_rows,
+                       int B, int L, int cin, int KK, int N, int pad, hipStream_t s) {
   switch (dtype) {
-    case EMB_F32: return launch_direct_t<float>(fwd, x, w, bias, out, partial, B, L, cin, KK, N, pad, s);
-    case EMB_BF16: return launch_direct_t<__bf16>(fwd, x, w, bias, out, partial, B, L, cin, KK, N, pad, s);
-    case EMB_F64: return launch_direct_t<double>(fwd, x, w, bias, out, partial, B, L, cin, KK, N, pad, s);
+    case EMB_F32: return launch_direct_t<float>(fwd, x, w, bias, out, partial, partial_rows, B, L, cin, KK, N, pad, s);
+    case EMB_BF16: return launch_direct_t<__bf16>(fwd, x, w, bias, out, partial, partial_rows, B, L, cin, KK, N, pad, s);
+    case EMB_F64: return launch_direct_t<double>(fwd, x, w, bias, out, partial, partial_rows, B, L, cin, KK, N, pad, s);
   }
   return EMB_ERR_DTYPE;
 }
@@ -281,32 +660,89 @@ __global__ __launch_bounds__(kThreads) void conv_wgrad_direct_kernel(const T* __
     for (int ni = 0; ni < NIW; ++ni)
 #pragma unroll
       for (int r = 0; r < 4; ++r) acc[mi][ni][r] = 0;
-  Acc bias_acc = 0;
+  // bias gradient (column sums of dy) rides on the matrix cores: dy^T x ones, accumulated by wave 0 of the nt == 0 workgroups
+  typename Mm::AccV bias_acc[MIW];
+#pragma unroll
+  for (int mi = 0; mi < MIW; ++mi)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) bias_acc[mi][r] = 0;
+  typename Mm::Frag ones;
+  if constexpr (BF) {
+#pragma unroll
+    for (int e = 0; e < 8; ++e) ones[e] = (T)1.0f;
+  } else {
+    ones = (T)1.0f;
+  }
+  const bool do_bias = nt == 0 && wave == 0;
 
   const int per = (tiles_m + S - 1) / S, tm_begin = slice * per, tm_end = min(tiles_m, tm_begin + per);
+  CONV_T(1, 0);
+  constexpr bool PF = sizeof(T) < 8;                       // register-staged prefetch (f64: direct staging)
+  constexpr int DV = BT * (BMW / VEC) / kThreads;          // dy-tile vectors per thread
+  const bool multi = L < BT;
+  XPlan<T> xp;
+  V xr[kXV], dr[DV];
+  int d_glb[DV], d_pk[DV];
+  if constexpr (PF) {
+    xplan_init<T>(xp, XS, xrows, SB, slot, L, cin, pad);
+#pragma unroll
+    for (int i = 0; i < DV; ++i) {
+      const int idx = threadIdx.x + i * kThreads;
+      const int r = idx / (BMW / VEC), cv = (idx % (BMW / VEC)) * VEC;
+      const int sq = multi ? r / L : 0, tl = multi ? r - sq * L : r;
+      d_glb[i] = (sq * L + tl) * Cout + o0 + cv;
+      d_pk[i] = ((multi ? r < SB * L : true) && o0 + cv < Cout) ? ((sq << 16) | tl) : -1;
+    }
+  }
+  auto issue = [&](int tm) {
+    const int b0 = (tm / tiles_t) * SB, t0 = (tm % tiles_t) * BT;
+    xplan_issue<T>(xp, xr, x, b0, t0, B, L, cin, pad);
+    const T* db = dy + ((long)b0 * L + t0) * Cout;
+#pragma unroll
+    for (int i = 0; i < DV; ++i) {
+      V val;
+#pragma unroll
+      for (int e = 0; e < VEC; ++e) val[e] = (T)0.0f;
+      if (d_pk[i] >= 0 && b0 + (d_pk[i] >> 16) < B && t0 + (d_pk[i] & 0xffff) < L) val = *reinterpret_cast<const V*>(db + d_glb[i]);
+      dr[i] = val;
+    }
+  };
+  if constexpr (PF) {
+    if (tm_begin < tm_end) issue(tm_begin);
+  }
   for (int tm = tm_begin; tm < tm_end; ++tm) {
     const int b0 = (tm / tiles_t) * SB, t0 = (tm % tiles_t) * BT;
     __syncthreads();   // previous tile fully consumed
-    stage_x_tile<T>(x, xs, XS, xrows, SB, slot, b0, t0, B, L, cin, pad);
-    for (int i = threadIdx.x; i < BT * (BMW / VEC); i += kThreads) {   // dy rows of this tile, zero where invalid
-      const int r = i / (BMW / VEC), cv = (i % (BMW / VEC)) * VEC;
-      const bool multi = L < BT;
-      const int s = multi ? r / L : 0, tl = multi ? r - s * L : r;
-      const bool rv = (multi ? r < SB * L : true) && (b0 + s < B) && (t0 + tl < L);
-      V v;
+    CONV_T(1, 1 + (tm - tm_begin) * 4 + 0);
+    if constexpr (PF) {
+      if (!CONV_DBG(3)) xplan_commit<T>(xp, xr, xs);
+      if (xrows * (cin / VEC) > kXV * kThreads) stage_x_tile<T>(x, xs, XS, xrows, SB, slot, b0, t0, B, L, cin, pad, kXV * kThreads);
 #pragma unroll
-      for (int e = 0; e < VEC; ++e) v[e] = (T)0.0f;
-      if (rv && o0 + cv < Cout) v = *reinterpret_cast<const V*>(dy + ((long)(b0 + s) * L + t0 + tl) * Cout + o0 + cv);
-      *reinterpret_cast<V*>(dys + r * DS + cv) = v;   // DS * sizeof(T) is a multiple of 16
+      for (int i = 0; i < (CONV_DBG(3) ? 0 : DV); ++i) {
+        const int idx = threadIdx.x + i * kThreads;
+        *reinterpret_cast<V*>(dys + (idx / (BMW / VEC)) * DS + (idx % (BMW / VEC)) * VEC) = dr[i];   // DS * sizeof(T) % 16 == 0
+      }
+    } else {
+      stage_x_tile<T>(x, xs, XS, xrows, SB, slot, b0, t0, B, L, cin, pad);
+      for (int i = threadIdx.x; i < BT * (BMW / VEC); i += kThreads) {   // dy rows of this tile, zero where invalid
+        const int r = i / (BMW / VEC), cv = (i % (BMW / VEC)) * VEC;
+        const int sq = multi ? r / L : 0, tl = multi ? r - sq * L : r;
+        const bool rv = (multi ? r < SB * L : true) && (b0 + sq < B) && (t0 + tl < L);
+        V v;
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) v[e] = (T)0.0f;
+        if (rv && o0 + cv < Cout) v = *reinterpret_cast<const V*>(dy + ((long)(b0 + sq) * L + t0 + tl) * Cout + o0 + cv);
+        *reinterpret_cast<V*>(dys + r * DS + cv) = v;
+      }
     }
     __syncthreads();
-    if (nt == 0 && threadIdx.x < BMW) {   // bias gradient: column sums of dy
-      Acc a = 0;
-      for (int r = 0; r < BT; ++r) a += (Acc)dys[r * DS + threadIdx.x];
-      bias_acc += a;
+    CONV_T(1, 1 + (tm - tm_begin) * 4 + 1);
+    if constexpr (PF) {
+      if (tm + 1 < tm_end && !CONV_DBG(2)) issue(tm + 1);   // in flight during this tile's MFMA loop
     }
-#pragma unroll 2
-    for (int ks = 0; ks < BT / KSTEP; ++ks) {
+    CONV_T(1, 1 + (tm - tm_begin) * 4 + 2);
+#pragma unroll 4
+    for (int ks = 0; ks < (CONV_DBG(0) ? 0 : BT / KSTEP); ++ks) {
       typename Mm::Frag af[MIW], bf[NIW];
       if (BF) {
         typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
@@ -341,7 +777,12 @@ __global__ __launch_bounds__(kThreads) void conv_wgrad_direct_kernel(const T* __
 #pragma unroll
           for (int mi = 0; mi < MIW; ++mi) acc[mi][ni] = Mm::mma(af[mi], bf[ni], acc[mi][ni]);
         }
+      if (do_bias && !CONV_DBG(1)) {
+#pragma unroll
+        for (int mi = 0; mi < MIW; ++mi) bias_acc[mi] = Mm::mma(af[mi], ones, bias_acc[mi]);
+      }
     }
+    CONV_T(1, 1 + (tm - tm_begin) * 4 + 3);
   }
   Acc* dst = slab + (long)slice * Cout * (KK + 1);
 #pragma unroll
@@ -353,7 +794,16 @@ __global__ __launch_bounds__(kThreads) void conv_wgrad_direct_kernel(const T* __
         const int o = o0 + mi * 16 + Mm::acc_row(lane, r), n = n0 + (ni * 4 + wave) * 16 + r16;
         if (o < Cout && n < KK) dst[(long)o * (KK + 1) + n] = acc[mi][ni][r];
       }
-  if (nt == 0 && threadIdx.x < BMW && o0 + threadIdx.x < Cout) dst[(long)(o0 + threadIdx.x) * (KK + 1) + KK] = bias_acc;
+  if (do_bias && r16 == 0) {   // every column of dy^T x ones holds the sum; lane column 0 writes it
+#pragma unroll
+    for (int mi = 0; mi < MIW; ++mi)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int o = o0 + mi * 16 + Mm::acc_row(lane, r);
+        if (o < Cout) dst[(long)o * (KK + 1) + KK] = bias_acc[mi][r];
+      }
+  }
+  CONV_T(1, 60);
 }
 
 template <typename T, int BMW> static size_t wgrad_direct_lds(int cin, int SB, int slot) {
@@ -413,5 +863,16 @@ int launch_conv_wgrad_direct(int dtype, const void* dy, const void* x, void* sla
   }
   return EMB_ERR_DTYPE;
 }
+
+#ifdef EMB_CONV_PROF
+extern "C" int emb_debug_conv_prof(unsigned long long* out, int select) {
+  int rc = (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_conv_prof), sizeof(unsigned long long) * 64);
+  unsigned long long z[64] = {};
+  (void)hipMemcpyToSymbol(HIP_SYMBOL(g_conv_prof), z, sizeof(z));
+  (void)hipMemcpyToSymbol(HIP_SYMBOL(g_conv_prof_sel), &select, sizeof(int));
+  return rc;
+}
+extern "C" int emb_debug_conv_dbg(int bits) { return (int)hipMemcpyToSymbol(HIP_SYMBOL(g_conv_dbg), &bits, sizeof(int)); }
+#endif
 
 }  // namespace emb

@@ -572,7 +572,7 @@ static int convblock_fwd(const void* x, const void* wpack, const void* bias, con
   const int R = B * L, KK = k * cin_pad, pad = (k - 1) / 2, Lp = (L - kPoolK) / kPoolS + 1;
   EMB_CHECK_ARG(Lp >= 1, "emb_convblock_fwd: sequence too short for the pooling window");
   int tiles_m = conv_tiling(B, L, pad).tiles_m;
-  int rc = launch_conv_direct(dtype_code<T>(), true, x, wpack, bias, y, ws, B, L, cin_pad, KK, Cout, pad, s);
+  int rc = launch_conv_direct(dtype_code<T>(), true, x, wpack, bias, y, ws, &tiles_m, B, L, cin_pad, KK, Cout, pad, s);
   if (rc == 1) {   // activation tile does not fit in LDS: generic GEMM on the im2col view
     if (Cout >= 64) rc = launch_conv_gemm<typename ConvCfg<T>::F64, true>(x, wpack, bias, y, ws, R, L, cin_pad, KK, Cout, pad, s);
     else rc = launch_conv_gemm<typename ConvCfg<T>::F32, true>(x, wpack, bias, y, ws, R, L, cin_pad, KK, Cout, pad, s);
@@ -650,7 +650,7 @@ static int convblock_bwd(const void* dout, int dout_ncl, const uint8_t* argmax, 
     EMB_CHECK_LAUNCH();
   }
   if (dx != nullptr) {   // dgrad: the same conv-view GEMM on dy with flipped taps
-    int rc = launch_conv_direct(dtype_code<T>(), false, dy, wflip, nullptr, dx, nullptr, B, L, Cout, k * Cout, cin_pad, pad, s);
+    int rc = launch_conv_direct(dtype_code<T>(), false, dy, wflip, nullptr, dx, nullptr, nullptr, B, L, Cout, k * Cout, cin_pad, pad, s);
     if (rc == 1) {
       if (cin_pad >= 64) rc = launch_conv_gemm<typename ConvCfg<T>::F64, false>(dy, wflip, nullptr, dx, nullptr, R, L, Cout, k * Cout, cin_pad, pad, s);
       else rc = launch_conv_gemm<typename ConvCfg<T>::F32, false>(dy, wflip, nullptr, dx, nullptr, R, L, Cout, k * Cout, cin_pad, pad, s);
