@@ -212,6 +212,7 @@ def main():
     loss_slot, conf_slot = table.slot()
     F = ea.functional
     model.train()
+    ticks = training.fused_ticks(model, opt, device)      # RNG step + optimizer step advance inside the loss kernel
     # N > 1: every gradient is a view of ONE flat buffer that the backward kernels write directly, so the
     # data-parallel reduction is a single in-place RCCL all-reduce.  Two trailing slots carry the NEXT step's
     # local (positives, rows): the global class counts a step needs before its loss are thus
@@ -224,7 +225,7 @@ def main():
             opt.zero_grad(set_to_none=True)
         out = model([x1, x2], is_training=True)
         _, dlogits = F.weighted_ce_with_grad(out, y, class_counts=counts, global_counts=world > 1, confusion=conf_slot,
-                                             loss_out=loss_slot)
+                                             loss_out=loss_slot, ticks=ticks)
         out.backward(dlogits)
 
     def reduce_grads():

@@ -114,9 +114,13 @@ int emb_linear_bwd(const void* dY, const uint8_t* mask, const void* X, const voi
  *   loss  [1] fp32 out: sum_i w[y_i] nll_i / sum_i w[y_i]  (local numerator / global denominator under DP)
  *   dlogits [B,2] T out (nullable): d loss / d logits
  *   confusion [4] int64 out (nullable): TP, predicted-positive, positive, n of THIS call's rows (written;
- *                the caller keeps one slot per step and evaluates AP / P / R / F1 once per epoch) */
+ *                the caller keeps one slot per step and evaluates AP / P / R / F1 once per epoch)
+ *   tick_a, tick_b uint64 device counters (nullable) incremented by one by this launch: a trainer passes the model's
+ *                RNG step counter (advances after every forward) and the optimizer's step counter (advances
+ *                before every update) so that a step needs no emb_counter_add launches */
 int emb_weighted_ce(const void* logits, const int64_t* target, int64_t* class_counts, int global_counts,
-                    float* loss, void* dlogits, int64_t* confusion, int B, int dtype, emb_stream_t stream);
+                    float* loss, void* dlogits, int64_t* confusion, uint64_t* tick_a, uint64_t* tick_b, int B,
+                    int dtype, emb_stream_t stream);
 
 /* counts positives of a label shard into class_counts[0..1] = (pos, n) (for the DP all-reduce) */
 int emb_count_labels(const int64_t* target, int64_t* class_counts, int B, emb_stream_t stream);

@@ -33,7 +33,7 @@ SIGNATURES = {
     "emb_embrace_bwd": [_vp] * 12 + [_vp, _i64, _i, _i, _i, _i, _i, _vp],
     "emb_linear_fwd": [_vp] * 5 + [_i, _f, _i, _u64, _u64, _vp, _i64, _i, _i, _i, _i, _vp],
     "emb_linear_bwd": [_vp] * 7 + [_i, _f, _vp, _i64, _i, _i, _i, _i, _vp],
-    "emb_weighted_ce": [_vp, _vp, _vp, _i, _vp, _vp, _vp, _i, _i, _vp],
+    "emb_weighted_ce": [_vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _vp, _i, _i, _vp],
     "emb_count_labels": [_vp, _vp, _i, _vp],
     "emb_adam_step": [_vp] * 5 + [_i64, _d, _d, _d, _d, _d, _u64, _vp, _i, _vp],
     "emb_rmsprop_step": [_vp] * 4 + [_i64, _d, _d, _d, _d, _i, _vp],

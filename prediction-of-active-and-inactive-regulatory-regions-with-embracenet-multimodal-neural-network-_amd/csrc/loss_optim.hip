@@ -27,7 +27,8 @@ template <typename T>
 __global__ __launch_bounds__(kCeThreads) void weighted_ce_kernel(const T* __restrict__ logits, const int64_t* __restrict__ target,
                                                                  int64_t* __restrict__ class_counts, int global_counts,
                                                                  float* __restrict__ loss, T* __restrict__ dlogits,
-                                                                 int64_t* __restrict__ confusion, int B) {
+                                                                 int64_t* __restrict__ confusion, uint64_t* __restrict__ tick_a,
+                                                                 uint64_t* __restrict__ tick_b, int B) {
   __shared__ double sd[kCeThreads];
   __shared__ long long sl[kCeThreads];
   const int tid = threadIdx.x;
@@ -80,6 +81,10 @@ __global__ __launch_bounds__(kCeThreads) void weighted_ce_kernel(const T* __rest
       confusion[2] = pos_local;
       confusion[3] = B;
     }
+    // step counters that advance once per loss evaluation (the model's RNG step after its forward, the optimizer's
+    // step before its update): folded in here so that a training step needs no counter launches of its own
+    if (tick_a != nullptr) tick_a[0] += 1;
+    if (tick_b != nullptr) tick_b[0] += 1;
   }
 }
 
@@ -190,14 +195,15 @@ template <typename S> static int cast_from(const void* src, void* dst, int dd, i
 using namespace emb;
 
 extern "C" int emb_weighted_ce(const void* logits, const int64_t* target, int64_t* class_counts, int global_counts, float* loss,
-                               void* dlogits, int64_t* confusion, int B, int dtype, emb_stream_t stream) {
+                               void* dlogits, int64_t* confusion, uint64_t* tick_a, uint64_t* tick_b, int B, int dtype,
+                               emb_stream_t stream) {
   EMB_CHECK_ARG(logits && target && class_counts && loss, "emb_weighted_ce: null pointer");
   EMB_CHECK_ARG(B > 0, "emb_weighted_ce: B must be positive (got %d)", B);
   hipStream_t s = (hipStream_t)stream;
   switch (dtype) {
-    case EMB_F32: weighted_ce_kernel<float><<<1, kCeThreads, 0, s>>>((const float*)logits, target, class_counts, global_counts, loss, (float*)dlogits, confusion, B); break;
-    case EMB_BF16: weighted_ce_kernel<__bf16><<<1, kCeThreads, 0, s>>>((const __bf16*)logits, target, class_counts, global_counts, loss, (__bf16*)dlogits, confusion, B); break;
-    case EMB_F64: weighted_ce_kernel<double><<<1, kCeThreads, 0, s>>>((const double*)logits, target, class_counts, global_counts, loss, (double*)dlogits, confusion, B); break;
+    case EMB_F32: weighted_ce_kernel<float><<<1, kCeThreads, 0, s>>>((const float*)logits, target, class_counts, global_counts, loss, (float*)dlogits, confusion, tick_a, tick_b, B); break;
+    case EMB_BF16: weighted_ce_kernel<__bf16><<<1, kCeThreads, 0, s>>>((const __bf16*)logits, target, class_counts, global_counts, loss, (__bf16*)dlogits, confusion, tick_a, tick_b, B); break;
+    case EMB_F64: weighted_ce_kernel<double><<<1, kCeThreads, 0, s>>>((const double*)logits, target, class_counts, global_counts, loss, (double*)dlogits, confusion, tick_a, tick_b, B); break;
     default: set_error("emb_weighted_ce: unsupported dtype %d", dtype); return EMB_ERR_DTYPE;
   }
   EMB_CHECK_LAUNCH();

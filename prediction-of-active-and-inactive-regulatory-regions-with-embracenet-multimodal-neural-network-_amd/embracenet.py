@@ -15,12 +15,17 @@ RNG
   element index); no host round trip, no device->host sync, graph-capturable, invariant to how the batch
   is sharded across GPUs.
 """
+import os
+
 import torch
 import torch.nn as nn
 
 from . import functional as F_
 from ._lib import STATUS_INVALID_DISTRIBUTION
 from .prenets import CNN_pre, FFNN_pre
+
+
+_SIDE_STREAMS = {}
 
 
 class _RngMixin:
@@ -194,6 +199,18 @@ class EmbraceNetMultimodal(nn.Module, _RngMixin):
         if T == torch.bfloat16 and not (self.FFNN.use_hip and self.CNN.use_hip):
             with torch.autocast("cuda", dtype=torch.bfloat16):          # stock-operator A/B path only
                 h0, h1 = self.FFNN(x_FFNN, rng=rng), self.CNN(x_CNN, rng=rng)
+        elif x_FFNN.is_cuda and getattr(self, "overlap_prenets", True) and not os.environ.get("EMB_NO_OVERLAP"):
+            # the two pre-networks are independent: the (tiny, launch-latency bound) epigenomic MLP runs on a side
+            # stream next to the sequence CNN.  autograd replays each node on its forward stream, so the two
+            # backward chains overlap as well; fork/join by events, which a stream capture records as graph edges
+            cur = torch.cuda.current_stream(dev)
+            side = self._side_stream(dev)
+            side.wait_stream(cur)
+            with torch.cuda.stream(side):
+                h0 = self.FFNN(x_FFNN, rng=rng)
+            h1 = self.CNN(x_CNN, rng=rng)
+            cur.wait_stream(side)
+            h0.record_stream(cur)
         else:
             h0, h1 = self.FFNN(x_FFNN, rng=rng), self.CNN(x_CNN, rng=rng)
         B = h0.shape[0]
@@ -215,5 +232,19 @@ class EmbraceNetMultimodal(nn.Module, _RngMixin):
         E = self.embracenet([h0, h1], availabilities=availabilities, selection_probabilities=p,
                             _device_dropout=device_dropout, _advance=False)
         out = self._post_forward(E, rng, T)
-        self.embracenet._advance_step()
+        if not getattr(self, "defer_step_tick", False):     # a trainer may fold the tick into its loss kernel (step_counter)
+            self.embracenet._advance_step()
         return out
+
+    def _side_stream(self, device):
+        st = _SIDE_STREAMS.get(device)          # per process and device, not an attribute: modules stay picklable
+        if st is None:
+            st = _SIDE_STREAMS[device] = torch.cuda.Stream(device=device)
+        return st
+
+    def step_counter(self, device):
+        """int64 device scalar added to the RNG step of every kernel of a forward.  It must advance by one after each
+        forward: `forward` does that with one tiny launch unless ``defer_step_tick`` is set, in which case the caller
+        hands this tensor to functional.weighted_ce_with_grad(ticks=...) (training.StepRunner does)."""
+        self.embracenet._rng_state(device)
+        return self.embracenet._step_dev

@@ -145,10 +145,13 @@ class _EmbraceFn(torch.autograd.Function):
         ctx.in_dtypes = (x0.dtype, x1.dtype, w0.dtype, b0.dtype, w1.dtype, b1.dtype)
         ctx.sinks = tuple(grad_sink(q, P) for q in (w0, b0, w1, b1))
         ctx.mark_non_differentiable(code)
+        ctx.set_materialize_grads(False)          # no zero tensor for the (non-differentiable) code output
         return E, code
 
     @staticmethod
     def backward(ctx, dE, _dcode):
+        if dE is None:
+            return (None,) * 10
         x0c, x1c, w0c, w1c, code = ctx.saved_tensors
         T = ctx.T
         P = PARAM_DTYPE[T]
@@ -324,7 +327,7 @@ class _WeightedCEFn(torch.autograd.Function):
         loss = loss_out if loss_out is not None else torch.empty(1, dtype=torch.float32, device=z.device)
         dz = torch.empty_like(z)
         check(_lib.lib().emb_weighted_ce(ptr(z), ptr(tgt), ptr(class_counts), int(bool(global_counts)), ptr(loss), ptr(dz),
-                                         ptr(confusion), B, DTYPE_CODE[T], stream()), "emb_weighted_ce")
+                                         ptr(confusion), None, None, B, DTYPE_CODE[T], stream()), "emb_weighted_ce")
         ctx.save_for_backward(dz)
         return loss.view(())
 
@@ -345,9 +348,11 @@ def weighted_ce(logits, target, class_counts=None, global_counts=False, confusio
     return _WeightedCEFn.apply(logits, target, class_counts, global_counts, confusion, loss_out)
 
 
-def weighted_ce_with_grad(logits, target, class_counts=None, global_counts=False, confusion=None, loss_out=None):
+def weighted_ce_with_grad(logits, target, class_counts=None, global_counts=False, confusion=None, loss_out=None, ticks=()):
     """Same kernel as `weighted_ce`, returning (loss [fp32 scalar, detached], dlogits) so that a trainer can call
-    ``logits.backward(dlogits)`` directly: the loss is the root of the graph and its own gradient is 1."""
+    ``logits.backward(dlogits)`` directly: the loss is the root of the graph and its own gradient is 1.
+    ticks: up to two int64 device counters the launch increments by one (the model's deferred RNG step, the
+    optimizer's step) -- see emb_weighted_ce."""
     _lib.require_cuda(logits, target)
     z = logits.detach()
     z = z if z.is_contiguous() else z.contiguous()
@@ -358,8 +363,12 @@ def weighted_ce_with_grad(logits, target, class_counts=None, global_counts=False
         class_counts = torch.empty(2, dtype=torch.int64, device=z.device)
     loss = loss_out if loss_out is not None else torch.empty(1, dtype=torch.float32, device=z.device)
     dz = torch.empty_like(z)
+    ticks = [t for t in ticks if t is not None]
+    if len(ticks) > 2:
+        raise ValueError("at most two tick counters")
+    ta, tb = (list(ticks) + [None, None])[:2]
     check(_lib.lib().emb_weighted_ce(ptr(z), ptr(tgt), ptr(class_counts), int(bool(global_counts)), ptr(loss), ptr(dz),
-                                     ptr(confusion), z.shape[0], DTYPE_CODE[z.dtype], stream()), "emb_weighted_ce")
+                                     ptr(confusion), ptr(ta), ptr(tb), z.shape[0], DTYPE_CODE[z.dtype], stream()), "emb_weighted_ce")
     return loss.view(()), dz
 
 
@@ -386,10 +395,13 @@ _WORKSPACE = {}
 
 
 def _workspace(device, nbytes):
-    buf = _WORKSPACE.get(device)
+    """Scratch buffer of the CURRENT stream (kernels of different streams may run concurrently: the epigenomic
+    pre-network overlaps the sequence pre-network, see EmbraceNetMultimodal.forward)."""
+    key = (device, torch.cuda.current_stream(device).cuda_stream)
+    buf = _WORKSPACE.get(key)
     if buf is None or buf.numel() < nbytes:
         buf = torch.empty(int(nbytes), dtype=torch.uint8, device=device)
-        _WORKSPACE[device] = buf
+        _WORKSPACE[key] = buf
     return buf
 
 

@@ -31,9 +31,17 @@ class _Fused(torch.optim.Optimizer):
         self._step_dev = {}
 
     def _counter(self, device):
+        device = torch.device(device)
+        if device.type == "cuda" and device.index is None:      # "cuda" and "cuda:0" must name the same counter
+            device = torch.device("cuda", torch.cuda.current_device())
         if device not in self._step_dev:
             self._step_dev[device] = torch.zeros(1, dtype=torch.int64, device=device)
         return self._step_dev[device]
+
+    def step_counter(self, device):
+        """int64 device scalar holding the number of updates done; `step` advances it before updating unless
+        ``external_tick`` is set (then functional.weighted_ce_with_grad(ticks=...) does, once per loss evaluation)."""
+        return self._counter(device)
 
     def _init_state(self, p, st):
         for name in self.state_names:
@@ -61,7 +69,8 @@ class _Fused(torch.optim.Optimizer):
                 buckets.setdefault((p.device, p.dtype), []).append(p)
             for (device, dtype), plist in buckets.items():
                 if device not in ticked:        # one tick per device per step, before any update of this step
-                    check(_lib.lib().emb_counter_add(ptr(self._counter(device)), 1, stream()), "emb_counter_add")
+                    if not getattr(self, "external_tick", False):   # else: advanced by the loss kernel (step_counter)
+                        check(_lib.lib().emb_counter_add(ptr(self._counter(device)), 1, stream()), "emb_counter_add")
                     ticked.add(device)
                 self._launch(group, plist, device, dtype)
         return loss

@@ -71,6 +71,20 @@ def _is_embracenet(model):
     return type(model).__name__ == 'EmbraceNetMultimodal'    # the reference switches on this string (:146)
 
 
+def fused_ticks(model, optimizer, device):
+    """Hands the per-step counters (the model's RNG step, the fused optimizer's update count) over to the loss kernel:
+    returns the tensors to pass as ``weighted_ce_with_grad(ticks=...)`` and switches the owners' own one-thread
+    counter launches off (two launches fewer per training step)."""
+    ticks = []
+    if hasattr(model, "step_counter"):
+        model.defer_step_tick = True
+        ticks.append(model.step_counter(device))
+    if optimizer is not None and hasattr(optimizer, "step_counter"):
+        optimizer.external_tick = True
+        ticks.append(optimizer.step_counter(device))
+    return tuple(ticks)
+
+
 class StepRunner:
     """One train or eval step of training_models_multimodal.py:132-163 / :167-192 on device tensors."""
 
@@ -78,6 +92,9 @@ class StepRunner:
         self.model, self.optimizer, self.device = model, optimizer, device
         self.bucket = D.GradBucket(model.parameters()) if optimizer is not None else None
         self.counts = torch.zeros(2, dtype=torch.int64, device=device)
+        on_gpu = torch.device(device).type == "cuda"
+        self.model_tick = model.step_counter(device) if (on_gpu and hasattr(model, "step_counter")) else None
+        self.opt_tick = optimizer.step_counter(device) if (on_gpu and optimizer is not None and hasattr(optimizer, "step_counter")) else None
 
     def _shard(self, x_1, x_2, target):
         world = D.world_size()
@@ -101,13 +118,21 @@ class StepRunner:
         if global_counts:                                   # class weights of the GLOBAL batch
             F_.count_labels(tgt, out=self.counts)
             D.allreduce_counts(self.counts)
-        if training and _is_embracenet(model):
-            output = model([x_1, x_2], is_training=True)
-        else:
-            output = model([x_1, x_2])
+        prev = getattr(model, "defer_step_tick", False)
+        if self.model_tick is not None:
+            model.defer_step_tick = True                    # the loss kernel below advances the RNG step
+        try:
+            if training and _is_embracenet(model):
+                output = model([x_1, x_2], is_training=True)
+            else:
+                output = model([x_1, x_2])
+        finally:
+            if self.model_tick is not None:
+                model.defer_step_tick = prev
         loss_slot, count_slot = table.slot()
+        ticks = (self.model_tick, self.opt_tick if training else None)
         loss, dlogits = F_.weighted_ce_with_grad(output, tgt, class_counts=self.counts, global_counts=global_counts,
-                                                 confusion=count_slot, loss_out=loss_slot)
+                                                 confusion=count_slot, loss_out=loss_slot, ticks=ticks)
         return output, loss, dlogits
 
     def train_step(self, x_1, x_2, target, table):
@@ -115,7 +140,13 @@ class StepRunner:
         output, loss, dlogits = self._forward_loss(x_1, x_2, target, True, table)
         output.backward(dlogits)        # the loss is the root of the graph: d loss / d logits comes from the loss kernel
         self.bucket.allreduce()
-        self.optimizer.step()
+        if self.opt_tick is not None:
+            self.optimizer.external_tick = True             # already advanced by the loss kernel of this step
+        try:
+            self.optimizer.step()
+        finally:
+            if self.opt_tick is not None:
+                self.optimizer.external_tick = False
         return output, loss
 
     def eval_step(self, x_1, x_2, target, table):
