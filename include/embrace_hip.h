@@ -188,7 +188,13 @@ int emb_nadam_step_multi(void* const* params, const void* const* grads, void* co
  *                         (the flatten order of CNN_pre.py:74); argmax[B][Lp][Cout] u8 (bits 0-3 window
  *                         offset of the maximum, bit 7 dropped).  Dropout mask: RNG kind 16+layer_id.
  *   emb_convblock_bwd     dout (layout as `out`) -> dx[B][L][cin_pad] T (nullable), dW[Cout][Cin][k] P (torch
- *                         layout), dbias, dgamma, dbeta [Cout] P; dy[B][L][Cout] T is caller-provided scratch. */
+ *                         layout), dbias, dgamma, dbeta [Cout] P; dy[B][L][Cout] T is caller-provided scratch.
+ *   emb_convblock_needs_y 0 for the FIRST block of the stack when its input has so few channels (cin_pad == 8, bf16,
+ *                         odd k <= 15, L <= 256, Cout in {16, 32, 64}) that the convolution is cheaper to recompute
+ *                         than to store: the caller then passes y = NULL to emb_convblock_fwd and y = dy = dx = NULL
+ *                         plus wpack and bias to emb_convblock_bwd, and the [B][L][Cout] tensors never exist
+ *                         (forward: statistics pass + fused conv/BN/ReLU/pool pass; backward: reduction pass + fused
+ *                         dz/weight-gradient pass).  The argmax byte then also carries bit 6 = pooled output is 0. */
 int64_t emb_convblock_workspace_bytes(int B, int L, int cin_pad, int Cout, int k, int dtype);
 int emb_ncl_to_nlc(const void* x, int src_dtype, void* out, int dst_dtype, int B, int C, int L, int Cpad,
                    emb_stream_t stream);
@@ -201,9 +207,11 @@ int emb_convblock_fwd(const void* x, const void* wpack, const void* bias, const 
                       int64_t workspace_bytes, int64_t* num_batches_tracked, int B, int L, int cin_pad, int Cout,
                       int k, int dtype, emb_stream_t stream);
 int emb_convblock_bwd(const void* dout, int dout_ncl, const uint8_t* argmax, const void* y, const void* stats,
-                      const void* x, const void* wflip, float dropout_p, int training, void* dx, void* dW,
-                      void* dbias, void* dgamma, void* dbeta, void* dy, void* workspace, int64_t workspace_bytes,
-                      int B, int L, int Cin, int cin_pad, int Cout, int k, int dtype, emb_stream_t stream);
+                      const void* x, const void* wflip, const void* wpack, const void* bias, float dropout_p,
+                      int training, void* dx, void* dW, void* dbias, void* dgamma, void* dbeta, void* dy,
+                      void* workspace, int64_t workspace_bytes, int B, int L, int Cin, int cin_pad, int Cout, int k,
+                      int dtype, emb_stream_t stream);
+int emb_convblock_needs_y(int B, int L, int cin_pad, int Cout, int k, int dtype);
 
 /* helpers: dtype conversion (fp32/fp64 master -> bf16 shadow etc.) and a device step counter */
 int emb_cast(const void* src, int src_dtype, void* dst, int dst_dtype, int64_t n, emb_stream_t stream);

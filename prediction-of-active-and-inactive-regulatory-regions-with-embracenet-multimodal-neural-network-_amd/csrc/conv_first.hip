@@ -1,0 +1,646 @@
+// The FIRST convolution block of the sequence pre-network (CNN_pre.py:37-44: Conv1d(4 -> C, k) -> BatchNorm1d -> ReLU ->
+// MaxPool1d(10, 2) -> Dropout on the one-hot DNA window) without ever materialising the convolution output.
+//
+// With 4 (padded: 8) input channels the convolution is ~60 MACs per output element, while its output -- [B, 256, C],
+// 33.5 MB in bf16 for the A549 shapes -- is the largest tensor of the whole training step and the stored-activation
+// path touches it seven times (conv write; BN/pool read; backward: read + dz write, read + read + dy write, wgrad read).
+// Here every pass RECOMPUTES the convolution on the matrix cores from the 4 MB input instead:
+//   forward   F_STATS   conv -> per-channel sums of z and z^2                       (no activation traffic)
+//             (bn_finalize_kernel)
+//             F_APPLY   conv -> BN -> ReLU -> LDS tile -> MaxPool/argmax/Dropout -> pooled output (16 MB) + argmax bytes
+//   backward  F_BSUMS   conv; gather of the pooled gradient through the argmax bytes -> sums of dy and dy*xhat
+//             (bn_bwd_finalize_kernel)
+//             F_BWGRAD  conv; gather; dz = A*dy + Bc*z + D -> LDS tile -> weight-gradient MFMAs -> per-workgroup slabs
+//             (conv_wgrad_reduce_kernel)
+// The input gradient does not exist (the one-hot input needs none), which is what makes the block fusable.
+// One workgroup tile = SB whole sequences (SB*L <= 256 rows), so pooling windows never cross a tile.  Layout and
+// MFMA mapping are those of the transposed streaming kernel (conv_direct.hip): channels on the MFMA M axis, weights in
+// registers, lane-group g owns 4*MT consecutive channels of its rows.  bf16 only (the fp32/fp64 paths keep the
+// stored-activation kernels).
+#include "conv_first.h"
+#include "conv_tiles.h"
+#include "philox.h"
+
+namespace emb {
+
+#ifdef EMB_CONV_PROF
+__device__ unsigned long long g_first_prof[64];
+__device__ int g_first_sel;
+#define FIRST_T(i) do { if (blockIdx.x == 0 && threadIdx.x == 0 && g_first_sel == MODE && (i) < 64) g_first_prof[i] = wall_clock64(); } while (0)
+#else
+#define FIRST_T(i) do {} while (0)
+#endif
+
+constexpr int kFBT = 256, kFXV = 2;            // rows per workgroup tile; activation vectors per thread (tile <= 512 rows)
+enum { F_STATS = 0, F_APPLY = 1, F_BSUMS = 2, F_BWGRAD = 3 };
+
+struct FirstArgs {
+  const __bf16* x;          // [B][L][8] channels-last, zero-padded channels
+  const __bf16* w;          // [C][KK] packed weights, KK = k*8
+  const float* bias;        // [C]
+  const float* stats;       // [4][C] mean, invstd, scale, shift (not read by F_STATS)
+  float* partial;           // F_STATS / F_BSUMS: [nblk][2][C]
+  __bf16* out;              // F_APPLY: pooled output, [B][Lp][C] or [B][C][Lp]
+  uint8_t* argmax;          // F_APPLY out / backward in: [B][Lp][C]
+  const __bf16* dout;       // backward: gradient of the pooled output (layout as `out`)
+  const float* coef;        // F_BWGRAD: [2][C] mean(dy), mean(dy*xhat)
+  float* slab;              // F_BWGRAD: [nblk][C][KK+1]
+  const uint64_t* step_dev;
+  uint64_t seed, step_val;
+  int64_t grow0;
+  float drop_p, keep_scale;
+  int ncl, training, layer_id;
+  int B, L, Lp, KK, C, pad, SB, slot, tiles_m, tpb;
+};
+
+__host__ __device__ constexpr int first_plo(int t) { return t >= 9 ? (t - 8) / 2 : 0; }   // first pooling window containing t
+
+// MT channel tiles (16 channels each) per wave, CH channel groups per workgroup: C = 16*MT*CH; 4*CH waves, wave = (row
+// quarter, channel group).  Splitting the channels over wave pairs halves the per-wave register state (weights, constants,
+// accumulators) so that 8 waves fit on a CU.
+template <int MT, int CH, int MODE>
+__global__ __launch_bounds__(256 * CH) void first_kernel(const FirstArgs a) {
+  using Mm = Mma<__bf16>;
+  using T = __bf16;
+  typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
+  constexpr int CPL = 4 * MT, GW = 16 * MT, BN = GW * CH, XS = 8, NW = 4 * CH, NTHR = 256 * CH;
+  constexpr int ZP = BN + 8;                            // pitch of the row-major bf16 tile (BN+ReLU output / dz)
+  extern __shared__ __attribute__((aligned(16))) char arena[];
+  const int L = a.L, Lp = a.Lp, C = a.C, SB = a.SB, slot = a.slot, KK = a.KK;
+  const int xrows = SB * slot + kXExtra, nks = (KK + 31) / 32;
+  // LDS carve
+  constexpr int DYP = BN + 4;                           // fp32 pitch of the pooled-gradient tile (backward)
+  T* xs = reinterpret_cast<T*>(arena);                                 // [xrows][8]
+  T* zt = xs + ((xrows * XS + 7) & ~7);                                // F_APPLY: [256][ZP] bf16
+  float* dyt = reinterpret_cast<float*>(zt);                           // backward: [256][DYP] fp32; F_BWGRAD overwrites each
+                                                                       // row's head with its dz in bf16 (pitch 2*DYP)
+  int* rowmap = reinterpret_cast<int*>(MODE >= F_BSUMS ? (char*)(dyt + kFBT * DYP) : (char*)(zt + (MODE == F_APPLY ? kFBT * ZP : 0)));
+  float* red = reinterpret_cast<float*>(rowmap + (MODE == F_BWGRAD ? kFBT : 0));                         // [4][2][BN]
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, g = lane >> 4, r16 = lane & 15;
+  const int grp = wave % CH, rq = wave / CH, gcol = grp * GW;   // channel group, row quarter, first channel of the group
+  const int bm = blockIdx.x, tm_begin = bm * a.tpb, tm_end = min(a.tiles_m, tm_begin + a.tpb);
+
+  FIRST_T(0);
+  // ---- this thread's share of the activation tile (tile independent)
+  int x_lds[kFXV], x_glb[kFXV], x_pk[kFXV];
+#pragma unroll
+  for (int i = 0; i < kFXV; ++i) {
+    const int row = threadIdx.x + i * NTHR, s = row / slot, dtp = row - s * slot;
+    x_lds[i] = row * XS;
+    x_glb[i] = (s * L + dtp - a.pad) * XS;
+    x_pk[i] = row < xrows ? (((s < SB ? s : 0x7fff) << 16) | dtp) : -1;
+  }
+  bf16x8 xr[kFXV];
+  auto issue_x = [&](int tm) {
+    const int b0 = tm * SB;
+    const T* xb = a.x + (long)b0 * L * XS;
+#pragma unroll
+    for (int i = 0; i < kFXV; ++i) {
+      bf16x8 v;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) v[e] = (T)0.0f;
+      if (x_pk[i] >= 0) {
+        const int s = x_pk[i] >> 16, tt = (x_pk[i] & 0xffff) - a.pad;
+        if (b0 + s < a.B && tt >= 0 && tt < L) v = *reinterpret_cast<const bf16x8*>(xb + x_glb[i]);
+      }
+      xr[i] = v;
+    }
+  };
+  if (tm_begin < tm_end) issue_x(tm_begin);
+
+  // ---- weights (A operand, channel-permuted rows) and per-channel constants of this lane's CPL channels
+  const int kl = 8 * g;
+  bf16x8 wf[MT][4];
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+      const int ch = gcol + chan_of<T, MT>(mt, r16), kk = ks * 32 + kl;
+      bf16x8 f;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) f[e] = (T)0.0f;
+      if (ch < C && kk < KK) f = *reinterpret_cast<const bf16x8*>(a.w + (long)ch * KK + kk);
+      wf[mt][ks] = f;
+    }
+  // per-channel constants with the conv bias folded in (acc = convolution without bias):
+  //   F_STATS   z = acc + k0                                  k0 = bias
+  //   F_APPLY   bn(z) = acc*k0 + k1                           k0 = scale, k1 = bias*scale + shift
+  //   F_BSUMS   xhat = (acc - k0)*k1                          k0 = mean - bias, k1 = invstd
+  //   F_BWGRAD  dz = k0*dy + k1*acc + k2                      bn_bwd_affine_kernel's A, Bc, D with z = acc + bias
+  float k0[MT][4], k1[MT][4], k2[MT][4];
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int ch = min(gcol + g * CPL + mt * 4 + r, C - 1);
+      const float bias = a.bias[ch];
+      k0[mt][r] = 0; k1[mt][r] = 0; k2[mt][r] = 0;
+      if (MODE == F_STATS) {
+        k0[mt][r] = bias;
+      } else if (MODE == F_APPLY) {
+        k0[mt][r] = a.stats[2 * C + ch];
+        k1[mt][r] = bias * k0[mt][r] + a.stats[3 * C + ch];
+      } else if (MODE == F_BSUMS) {
+        k0[mt][r] = a.stats[ch] - bias;
+        k1[mt][r] = a.stats[C + ch];
+      } else {
+        const float mean = a.stats[ch], inv = a.stats[C + ch], sc = a.stats[2 * C + ch];
+        const float bc = a.training ? -sc * a.coef[C + ch] * inv : 0.0f;
+        const float d = a.training ? sc * (a.coef[C + ch] * inv * mean - a.coef[ch]) : 0.0f;
+        k0[mt][r] = sc;
+        k1[mt][r] = bc;
+        k2[mt][r] = bc * bias + d;
+      }
+    }
+  float s1[MT][4], s2[MT][4];   // F_STATS: sum z, z^2;  F_BSUMS: sum dy, dy*xhat
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) { s1[mt][r] = 0; s2[mt][r] = 0; }
+
+  // ---- this lane's output rows
+  int xrow[4], row_sq[4], row_t[4];      // LDS row of tap 0; sequence slot; time (-1: row past the tile's sequences)
+#pragma unroll
+  for (int nt = 0; nt < 4; ++nt) {
+    const int row = rq * 64 + nt * 16 + r16;
+    const int rr = min(row, SB * L - 1), sq = rr / L;
+    xrow[nt] = sq * slot + (rr - sq * L);
+    row_sq[nt] = sq;
+    row_t[nt] = row < SB * L ? rr - sq * L : -1;
+  }
+  if (MODE == F_BWGRAD && threadIdx.x < kFBT) {
+    const int row = threadIdx.x, rr = min(row, SB * L - 1), sq = rr / L;
+    rowmap[row] = sq * slot + (rr - sq * L);
+  }
+  // weight-gradient accumulators: all MIW channel tiles x this wave's n-blocks (16 columns of k*8) nb = ni*NW + wave
+  constexpr int MIW = MT * CH, NIW = 8 / NW;
+  typename Mm::AccV accw[MODE == F_BWGRAD ? MIW : 1][NIW];
+  if (MODE == F_BWGRAD) {
+#pragma unroll
+    for (int mi = 0; mi < MIW; ++mi)
+#pragma unroll
+      for (int ni = 0; ni < NIW; ++ni)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) accw[mi][ni][r] = 0;
+  }
+  const int q4 = r16 >> 2, p4 = r16 & 3;
+  // ---- this thread's pooled-tensor items (window p of sequence slot sq, 8 channels from c0): tile independent, so the
+  // index arithmetic (runtime divisions) happens once per kernel, not per tile and phase
+  constexpr int NIT = 1024 / NTHR, CV = BN / 8;        // SB * Lp * C / 8 <= 1024 items per tile
+  int it_row[NIT], it_pc[NIT];                         // tile row of the window start | (c0 << 16);  p | sq << 8 | (p % 5) << 16; -1 none
+  if (MODE != F_STATS) {
+#pragma unroll
+    for (int i = 0; i < NIT; ++i) {
+      const int it = threadIdx.x + i * NTHR, c0 = (it % CV) * 8, sp = it / CV, sq = sp / Lp, p = sp - sq * Lp;
+      it_row[i] = (sq * L + 2 * p) | (c0 << 16);
+      it_pc[i] = sq < SB ? (p | (sq << 8) | ((p % 5) << 16)) : -1;
+    }
+  }
+
+  FIRST_T(1);
+  for (int tm = tm_begin; tm < tm_end; ++tm) {
+    const int b0 = tm * SB, nseq = min(SB, a.B - b0);
+    __syncthreads();                                   // previous tile's LDS contents are consumed
+    FIRST_T(2 + (tm - tm_begin) * 8 + 0);
+#pragma unroll
+    for (int i = 0; i < kFXV; ++i)
+      if (x_pk[i] >= 0) *reinterpret_cast<bf16x8*>(xs + x_lds[i]) = xr[i];
+    if (MODE >= F_BSUMS) {
+      // dy tile: every pooled gradient element lands on the row its window's argmax points to.  Windows p and p' share rows
+      // only when |p - p'| < 5, so five barrier-separated phases (p mod 5) make the LDS adds conflict free and their
+      // order fixed (deterministic sums).  ReLU zeros / dropped elements carry bit 6 / 7 in the byte and are skipped.
+      for (int i = threadIdx.x * 4; i < kFBT * DYP; i += NTHR * 4) *reinterpret_cast<float4*>(dyt + i) = make_float4(0.f, 0.f, 0.f, 0.f);
+      bf16x8 gv[NIT];
+      uint64_t av[NIT];
+      if (!a.ncl) {
+        const T* gsrc = a.dout + (long)b0 * Lp * C;
+        const uint8_t* asrc = a.argmax + (long)b0 * Lp * C;
+#pragma unroll
+        for (int i = 0; i < NIT; ++i) {
+          if (it_pc[i] >= 0 && ((it_pc[i] >> 8) & 0xFF) < nseq) {
+            const long off = (long)(threadIdx.x + i * NTHR) * 8;     // items are laid out exactly as [sq][p][c]
+            gv[i] = *reinterpret_cast<const bf16x8*>(gsrc + off);
+            av[i] = *reinterpret_cast<const uint64_t*>(asrc + off);
+          }
+        }
+      }
+      __syncthreads();                                  // zero fill complete
+      FIRST_T(2 + (tm - tm_begin) * 8 + 1);
+      if (!a.ncl) {
+        for (int ph = 0; ph < 5; ++ph) {
+#pragma unroll
+          for (int i = 0; i < NIT; ++i) {
+            if (it_pc[i] >= 0 && ((it_pc[i] >> 8) & 0xFF) < nseq && (it_pc[i] >> 16) == ph) {
+              float* rowbase = dyt + (it_row[i] & 0xFFFF) * DYP + (it_row[i] >> 16);
+              // read-modify-write, branch free: all eight reads in flight before the first write; an element without a
+              // target (ReLU zero / dropped) rewrites its own window-start cell, which nobody else touches in this phase
+              int off[8];
+              float old[8];
+#pragma unroll
+              for (int e = 0; e < 8; ++e) {
+                const int code = (int)((av[i] >> (8 * e)) & 0xFF);
+                off[e] = (code < 0x40 ? code * DYP : 0) + e;
+                old[e] = rowbase[off[e]];
+              }
+#pragma unroll
+              for (int e = 0; e < 8; ++e) {
+                const int code = (int)((av[i] >> (8 * e)) & 0xFF);
+                rowbase[off[e]] = old[e] + (code < 0x40 ? (float)gv[i][e] * a.keep_scale : 0.0f);
+              }
+            }
+          }
+          __syncthreads();
+        }
+      } else {                                          // dout[b][c][p] (single-block stack): element-wise, same phases
+        for (int ph = 0; ph < 5; ++ph) {
+          for (int i = threadIdx.x; i < nseq * C * Lp; i += NTHR) {
+            const int sq = i / (C * Lp), rem = i - sq * C * Lp, c = rem / Lp, p = rem - c * Lp;
+            if (p % 5 == ph) {
+              const int code = a.argmax[((long)(b0 + sq) * Lp + p) * C + c];
+              if (code < 0x40) dyt[(sq * L + 2 * p + code) * DYP + c] += (float)a.dout[((long)(b0 + sq) * C + c) * Lp + p] * a.keep_scale;
+            }
+          }
+          __syncthreads();
+        }
+      }
+    }
+    __syncthreads();
+    FIRST_T(2 + (tm - tm_begin) * 8 + 2);
+    if (tm + 1 < tm_end) issue_x(tm + 1);
+
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {                      // two row tiles at a time (accumulator registers)
+      __builtin_amdgcn_sched_barrier(0);               // keep the two halves apart: interleaving them doubles the live registers
+      typename Mm::AccV acc[MT][2];
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) acc[mt][j][r] = 0;
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) {
+        if (ks < nks) {
+          bf16x8 bf[2];
+#pragma unroll
+          for (int j = 0; j < 2; ++j)                  // cin == 8: k-step ks, lane-group g reads tap 4*ks + g: one LDS row
+            bf[j] = *reinterpret_cast<const bf16x8*>(xs + (xrow[2 * h + j] + 4 * ks + g) * XS);
+#pragma unroll
+          for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) acc[mt][j] = Mm::mma(wf[mt][ks], bf[j], acc[mt][j]);
+        }
+      }
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        const int nt = 2 * h + j, sq = row_sq[nt], t = row_t[nt];
+        const bool rv = t >= 0 && sq < nseq;
+        const int row = rq * 64 + nt * 16 + r16;
+        if (MODE == F_STATS) {
+          if (rv) {
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+              for (int r = 0; r < 4; ++r) {
+                const float z = acc[mt][j][r] + k0[mt][r];
+                s1[mt][r] += z;
+                s2[mt][r] += z * z;
+              }
+          }
+        } else if (MODE == F_APPLY) {
+          T ov[CPL];
+#pragma unroll
+          for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+              const float z = acc[mt][j][r] * k0[mt][r] + k1[mt][r];
+              ov[mt * 4 + r] = (T)(z > 0.0f ? z : 0.0f);
+            }
+          T* dst = zt + row * ZP + gcol + g * CPL;
+          if (CPL >= 8) {
+#pragma unroll
+            for (int qv = 0; qv < CPL / 8; ++qv) {
+              bf16x8 o;
+#pragma unroll
+              for (int e = 0; e < 8; ++e) o[e] = ov[qv * 8 + e];
+              *reinterpret_cast<bf16x8*>(dst + qv * 8) = o;
+            }
+          } else {
+            bf16x4 o = {ov[0], ov[1], ov[2], ov[3]};
+            *reinterpret_cast<bf16x4*>(dst) = o;
+          }
+        } else {
+          // this lane's CPL channels of its row of the pooled-gradient tile
+          float dy[CPL];
+          {
+            const float* src = dyt + row * DYP + gcol + g * CPL;
+#pragma unroll
+            for (int qv = 0; qv < CPL / 4; ++qv) {
+              const float4 v = *reinterpret_cast<const float4*>(src + qv * 4);
+              dy[qv * 4 + 0] = v.x; dy[qv * 4 + 1] = v.y; dy[qv * 4 + 2] = v.z; dy[qv * 4 + 3] = v.w;
+            }
+          }
+          if (MODE == F_BSUMS) {
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+              for (int r = 0; r < 4; ++r) {
+                const float d = dy[mt * 4 + r];
+                s1[mt][r] += d;
+                s2[mt][r] += d * ((acc[mt][j][r] - k0[mt][r]) * k1[mt][r]);
+              }
+          } else {   // F_BWGRAD
+            T ov[CPL];
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+              for (int r = 0; r < 4; ++r) {
+                const float dz = k0[mt][r] * dy[mt * 4 + r] + k1[mt][r] * acc[mt][j][r] + k2[mt][r];
+                ov[mt * 4 + r] = (T)(rv ? dz : 0.0f);
+              }
+            // in place: the four lane-groups of a row are lanes of THIS wave and have all read their dy above
+            T* dst = zt + row * (2 * DYP) + gcol + g * CPL;
+            if (CPL >= 8) {
+#pragma unroll
+              for (int qv = 0; qv < CPL / 8; ++qv) {
+                bf16x8 o;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) o[e] = ov[qv * 8 + e];
+                *reinterpret_cast<bf16x8*>(dst + qv * 8) = o;
+              }
+            } else {
+              bf16x4 o = {ov[0], ov[1], ov[2], ov[3]};
+              *reinterpret_cast<bf16x4*>(dst) = o;
+            }
+          }
+        }
+      }
+    }
+
+    FIRST_T(2 + (tm - tm_begin) * 8 + 3);
+    if (MODE == F_APPLY) {
+      __syncthreads();
+      // MaxPool(10, 2) + argmax + Dropout over the tile's sequences; thread = (sequence, window, 8 channels)
+      float keep_scale = 1.0f;
+      uint64_t stream = 0;
+      if (a.drop_p > 0.0f) {
+        keep_scale = 1.0f / (1.0f - a.drop_p);
+        stream = rng_stream(a.step_val + (a.step_dev ? *a.step_dev : 0), EMB_RNG_DROPOUT0 + a.layer_id);
+      }
+#pragma unroll
+      for (int i = 0; i < NIT; ++i) {
+        if (it_pc[i] < 0 || ((it_pc[i] >> 8) & 0xFF) >= nseq) continue;
+        const int c0 = it_row[i] >> 16, p = it_pc[i] & 0xFF, b = b0 + ((it_pc[i] >> 8) & 0xFF);
+        const T* base = zt + (it_row[i] & 0xFFFF) * ZP + c0;
+        // max and argmax in ONE unsigned max per element and row: post-ReLU bf16 values are >= 0, so their bit patterns
+        // order like the values; widened to the high half of a word, the low bits carry 9 - row (ties keep the first row,
+        // as torch does)
+        uint32_t key[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) key[e] = 0;
+#pragma unroll
+        for (int wdw = 0; wdw < 10; ++wdw) {
+          const uint4 v = *reinterpret_cast<const uint4*>(base + wdw * ZP);
+          const uint32_t wd[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            key[2 * q] = max(key[2 * q], (wd[q] << 16) | (uint32_t)(9 - wdw));
+            key[2 * q + 1] = max(key[2 * q + 1], (wd[q] & 0xffff0000u) | (uint32_t)(9 - wdw));
+          }
+        }
+        float best[8];
+        int arg[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          best[e] = __uint_as_float(key[e] & 0xffff0000u);
+          arg[e] = 9 - (int)(key[e] & 0xFu);
+        }
+        uint64_t amv = 0;
+        bf16x8 o;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          float z = best[e];
+          int code = arg[e] | (z > 0.0f ? 0 : 0x40);          // bit 6: ReLU output is zero -> no gradient
+          if (a.drop_p > 0.0f) {
+            const uint64_t idx = ((uint64_t)(a.grow0 + b) * Lp + p) * C + c0 + e;
+            const bool keep = uniform24(philox4x32_10(a.seed, stream, idx).x) >= a.drop_p;
+            z = keep ? z * keep_scale : 0.0f;
+            code |= keep ? 0 : 0x80;
+          }
+          o[e] = (T)z;
+          amv |= (uint64_t)(uint8_t)code << (8 * e);
+        }
+        const long nlc = ((long)b * Lp + p) * C + c0;
+        *reinterpret_cast<uint64_t*>(a.argmax + nlc) = amv;
+        if (a.ncl) {
+#pragma unroll
+          for (int e = 0; e < 8; ++e) a.out[((long)b * C + c0 + e) * Lp + p] = o[e];
+        } else {
+          *reinterpret_cast<bf16x8*>(a.out + nlc) = o;
+        }
+      }
+    }
+
+    FIRST_T(2 + (tm - tm_begin) * 8 + 4);
+    if (MODE == F_BWGRAD) {
+      __syncthreads();
+      // dW[o][n] += sum_r dz[r][o] * xview[r][n]:  A = dz^T (tr16 reads of the row-major tile), B = x view, K = 256 rows.
+      // column KK of the B operand is forced to ones: slab column KK = sum_r dz = bias gradient
+      const int nb_bias = KK >> 4, lane_bias = KK & 15;
+#pragma unroll 2
+      for (int ks = 0; ks < kFBT / 32; ++ks) {
+        const int ra = ks * 32 + 8 * g + q4;
+        bf16x8 af[MIW], bfw[NIW];
+#pragma unroll
+        for (int mi = 0; mi < MIW; ++mi) {
+          const T* a0 = zt + ra * (2 * DYP) + mi * 16 + 4 * p4;
+          union { struct { s16x4 lo, hi; } s; bf16x8 v; } u;
+          u.s.lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(a0));
+          u.s.hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(a0 + 4 * (2 * DYP)));
+          af[mi] = u.v;
+        }
+        const int x0 = rowmap[ra] * XS, x1 = rowmap[ra + 4] * XS;
+#pragma unroll
+        for (int ni = 0; ni < NIW; ++ni) {
+          const int nb = ni * NW + wave, xoff = nb * 16 + 4 * p4;   // column n = tap*8 + ci = LDS offset (pitch 8)
+          union { struct { s16x4 lo, hi; } s; bf16x8 v; } u;
+          u.s.lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(xs + x0 + xoff));
+          u.s.hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(xs + x1 + xoff));
+          bfw[ni] = u.v;
+          if (nb == nb_bias && r16 == lane_bias) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) bfw[ni][e] = (T)1.0f;
+          }
+        }
+#pragma unroll
+        for (int ni = 0; ni < NIW; ++ni)
+#pragma unroll
+          for (int mi = 0; mi < MIW; ++mi) accw[mi][ni] = Mm::mma(af[mi], bfw[ni], accw[mi][ni]);
+      }
+    }
+  }
+
+  FIRST_T(40);
+  if (MODE == F_STATS || MODE == F_BSUMS) {   // one partial row per workgroup
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const float sa = row16_sum<float>(s1[mt][r]), sb = row16_sum<float>(s2[mt][r]);
+        if (r16 == 0) {
+          red[(rq * 2 + 0) * BN + gcol + g * CPL + mt * 4 + r] = sa;
+          red[(rq * 2 + 1) * BN + gcol + g * CPL + mt * 4 + r] = sb;
+        }
+      }
+    __syncthreads();
+    if (threadIdx.x < 2 * BN) {   // the four row quarters, in order
+      const int c = threadIdx.x % BN, which = threadIdx.x / BN;
+      if (c < C)
+        a.partial[((long)bm * 2 + which) * C + c] =
+            ((red[(0 * 2 + which) * BN + c] + red[(1 * 2 + which) * BN + c]) + red[(2 * 2 + which) * BN + c]) + red[(3 * 2 + which) * BN + c];
+    }
+  }
+  if (MODE == F_BWGRAD) {
+    float* dst = a.slab + (long)bm * C * (KK + 1);
+#pragma unroll
+    for (int mi = 0; mi < MIW; ++mi)
+#pragma unroll
+      for (int ni = 0; ni < NIW; ++ni)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int o = mi * 16 + Mm::acc_row(lane, r), n = (ni * NW + wave) * 16 + r16;
+          if (o < C && n <= KK) dst[(long)o * (KK + 1) + n] = accw[mi][ni][r];
+        }
+  }
+  FIRST_T(41);
+}
+
+#ifdef EMB_CONV_PROF
+extern "C" int emb_debug_first_prof(unsigned long long* out, int select) {
+  int rc = (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_first_prof), sizeof(unsigned long long) * 64);
+  unsigned long long z[64] = {};
+  (void)hipMemcpyToSymbol(HIP_SYMBOL(g_first_prof), z, sizeof(z));
+  (void)hipMemcpyToSymbol(HIP_SYMBOL(g_first_sel), &select, sizeof(int));
+  return rc;
+}
+#endif
+
+// ------------------------------------------------------------------------------------------------- host side
+struct FirstGeom {
+  int SB, slot, tiles_m, tpb, nblk, xrows;
+};
+
+static bool first_geom(int B, int L, int cin_pad, int Cout, int k, FirstGeom* gm) {
+  const int pad = (k - 1) / 2, KK = k * 8, Lp = (L - 10) / 2 + 1;
+  if (cin_pad != 8 || (k & 1) == 0 || KK >= 128 || L < 10 || L > kFBT || Lp < 1) return false;
+  if (Cout != 16 && Cout != 32 && Cout != 64) return false;
+  gm->SB = kFBT / L;
+  gm->slot = L + 2 * pad;
+  gm->xrows = gm->SB * gm->slot + kXExtra;
+  if (gm->xrows > 256 * kFXV) return false;   // (512-thread variants stage more per slot; 256 is the common bound)
+  if ((long)gm->SB * ((L - 10) / 2 + 1) * Cout / 8 > 1024) return false;   // pooled-gradient items per thread (NIT)
+  gm->tiles_m = cdiv(B, gm->SB);
+  const int target = Cout == 64 ? 256 : 512;                            // 8 waves per CU: one 8-wave or two 4-wave workgroups
+  gm->tpb = cdiv(gm->tiles_m, target) < 1 ? 1 : cdiv(gm->tiles_m, target);
+  gm->nblk = cdiv(gm->tiles_m, gm->tpb);
+  return true;
+}
+
+static size_t first_lds(int mode, const FirstGeom& gm, int Lp, int C) {
+  const int BN = C, ZP = BN + 8, DYP = BN + 4;
+  size_t bytes = (((size_t)gm.xrows * 8 + 7) & ~(size_t)7) * 2;
+  if (mode == F_APPLY) bytes += (size_t)kFBT * ZP * 2;
+  if (mode >= F_BSUMS) bytes += (size_t)kFBT * DYP * 4;
+  if (mode == F_BWGRAD) bytes += kFBT * sizeof(int);
+  bytes += (size_t)4 * 2 * BN * sizeof(float);
+  return (bytes + 15) & ~(size_t)15;
+}
+
+int conv_first_supported(int dtype, int B, int L, int cin_pad, int Cout, int k) {
+  FirstGeom gm;
+  if (dtype != EMB_BF16 || !first_geom(B, L, cin_pad, Cout, k, &gm)) return 0;
+  const int Lp = (L - 10) / 2 + 1;
+  return first_lds(F_BWGRAD, gm, Lp, Cout) <= 150 * 1024 ? 1 : 0;
+}
+
+int conv_first_blocks(int B, int L, int cin_pad, int Cout, int k) {
+  FirstGeom gm;
+  return first_geom(B, L, cin_pad, Cout, k, &gm) ? gm.nblk : 0;
+}
+
+template <int MODE> static int first_launch(FirstArgs& a, const FirstGeom& gm, hipStream_t s) {
+  const size_t lds = first_lds(MODE, gm, a.Lp, a.C);
+  auto go = [&](auto kern, int threads) {
+    static bool attr = false;
+    if (!attr) {
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
+      attr = true;
+    }
+    kern<<<gm.nblk, threads, lds, s>>>(a);
+  };
+  switch (a.C) {
+    case 16: go(&first_kernel<1, 1, MODE>, 256); break;
+    case 32: go(&first_kernel<2, 1, MODE>, 256); break;
+    default: go(&first_kernel<2, 2, MODE>, 512); break;
+  }
+  EMB_CHECK_LAUNCH();
+  return EMB_OK;
+}
+
+static void first_fill(FirstArgs& a, const FirstGeom& gm, int B, int L, int Cout, int k) {
+  a.B = B; a.L = L; a.Lp = (L - 10) / 2 + 1; a.KK = k * 8; a.C = Cout; a.pad = (k - 1) / 2;
+  a.SB = gm.SB; a.slot = gm.slot; a.tiles_m = gm.tiles_m; a.tpb = gm.tpb;
+}
+
+int conv_first_stats(const void* x, const void* w, const void* bias, void* partial, int* rows, int B, int L, int Cout, int k,
+                     hipStream_t s) {
+  FirstGeom gm;
+  if (!first_geom(B, L, 8, Cout, k, &gm)) return 1;
+  FirstArgs a{};
+  first_fill(a, gm, B, L, Cout, k);
+  a.x = (const __bf16*)x; a.w = (const __bf16*)w; a.bias = (const float*)bias; a.partial = (float*)partial;
+  *rows = gm.nblk;
+  return first_launch<F_STATS>(a, gm, s);
+}
+
+int conv_first_apply(const void* x, const void* w, const void* bias, const void* stats, void* out, uint8_t* argmax, int out_ncl,
+                     float drop_p, uint64_t seed, uint64_t step_val, const uint64_t* step_dev, int64_t row0, int layer_id, int B, int L,
+                     int Cout, int k, hipStream_t s) {
+  FirstGeom gm;
+  if (!first_geom(B, L, 8, Cout, k, &gm)) return 1;
+  FirstArgs a{};
+  first_fill(a, gm, B, L, Cout, k);
+  a.x = (const __bf16*)x; a.w = (const __bf16*)w; a.bias = (const float*)bias; a.stats = (const float*)stats;
+  a.out = (__bf16*)out; a.argmax = argmax; a.ncl = out_ncl; a.drop_p = drop_p; a.seed = seed; a.step_val = step_val;
+  a.step_dev = step_dev; a.grow0 = row0; a.layer_id = layer_id;
+  return first_launch<F_APPLY>(a, gm, s);
+}
+
+int conv_first_bwd_sums(const void* dout, int dout_ncl, const uint8_t* argmax, const void* x, const void* w, const void* bias,
+                        const void* stats, float keep_scale, void* bpart, int* rows, int B, int L, int Cout, int k, hipStream_t s) {
+  FirstGeom gm;
+  if (!first_geom(B, L, 8, Cout, k, &gm)) return 1;
+  FirstArgs a{};
+  first_fill(a, gm, B, L, Cout, k);
+  a.x = (const __bf16*)x; a.w = (const __bf16*)w; a.bias = (const float*)bias; a.stats = (const float*)stats;
+  a.dout = (const __bf16*)dout; a.ncl = dout_ncl; a.argmax = const_cast<uint8_t*>(argmax); a.keep_scale = keep_scale;
+  a.partial = (float*)bpart;
+  *rows = gm.nblk;
+  return first_launch<F_BSUMS>(a, gm, s);
+}
+
+int conv_first_bwd_wgrad(const void* dout, int dout_ncl, const uint8_t* argmax, const void* x, const void* w, const void* bias,
+                         const void* stats, const void* coef, float keep_scale, int training, void* slab, int* slices, int B, int L,
+                         int Cout, int k, hipStream_t s) {
+  FirstGeom gm;
+  if (!first_geom(B, L, 8, Cout, k, &gm)) return 1;
+  FirstArgs a{};
+  first_fill(a, gm, B, L, Cout, k);
+  a.x = (const __bf16*)x; a.w = (const __bf16*)w; a.bias = (const float*)bias; a.stats = (const float*)stats;
+  a.dout = (const __bf16*)dout; a.ncl = dout_ncl; a.argmax = const_cast<uint8_t*>(argmax); a.keep_scale = keep_scale;
+  a.coef = (const float*)coef; a.training = training; a.slab = (float*)slab;
+  *slices = gm.nblk;
+  return first_launch<F_BWGRAD>(a, gm, s);
+}
+
+}  // namespace emb

@@ -444,7 +444,9 @@ class _ConvStackFn(torch.autograd.Function):
                                           stream()), "emb_conv_pack_weight")
             Lp = pool_out_len(L)
             last = i == n_layers - 1
-            y = torch.empty(B, L, Cout, dtype=T, device=dev)
+            # first block with a few-channel input: recomputed in every pass instead of stored (csrc/conv_first.hip)
+            fused = i == 0 and L_.emb_convblock_needs_y(B, L, cin_pad, Cout, k, code) == 0
+            y = None if fused else torch.empty(B, L, Cout, dtype=T, device=dev)
             stats = torch.empty(4, Cout, dtype=P, device=dev)
             out = torch.empty((B, Cout, Lp) if last else (B, Lp, Cout), dtype=T, device=dev)
             argmax = torch.empty(B, Lp, Cout, dtype=torch.uint8, device=dev)
@@ -455,8 +457,8 @@ class _ConvStackFn(torch.autograd.Function):
                                        rng.seed, rng.step_val, ptr(rng.step_dev), rng.row0, int(m["layer_id"]), ptr(y),
                                        ptr(stats), ptr(out), ptr(argmax), int(last), ptr(ws), ws.numel(), ptr(nbt), B, L,
                                        cin_pad, Cout, k, code, stream()), "emb_convblock_fwd")
-            saved += [cur, y, stats, argmax, wflip if wflip is not None else stats]
-            shapes.append((L, Cin, cin_pad, Cout, k, float(m["drop_p"])))
+            saved += [cur, y if y is not None else stats, stats, argmax, wflip if wflip is not None else stats, wpack, b.detach()]
+            shapes.append((L, Cin, cin_pad, Cout, k, float(m["drop_p"]), fused))
             cur, L, cin_pad = out, Lp, Cout
         ctx.save_for_backward(*saved)
         ctx.cfg = (T, int(training), B, shapes)
@@ -474,18 +476,19 @@ class _ConvStackFn(torch.autograd.Function):
         g = _as(dout, T)
         grads = [None] * (6 * len(shapes))
         for i in reversed(range(len(shapes))):
-            xin, y, stats, argmax, wflip = saved[5 * i:5 * i + 5]
-            L, Cin, cin_pad, Cout, k, drop_p = shapes[i]
+            xin, y, stats, argmax, wflip, wpack, bias = saved[7 * i:7 * i + 7]
+            L, Cin, cin_pad, Cout, k, drop_p, fused = shapes[i]
             last = i == len(shapes) - 1
-            dy = torch.empty(B, L, Cout, dtype=T, device=dev)
+            dy = None if fused else torch.empty(B, L, Cout, dtype=T, device=dev)
             dx = torch.empty(B, L, cin_pad, dtype=T, device=dev) if i > 0 else None
             sk = ctx.sinks[4 * i:4 * i + 4]
             dW = _out(sk[0], (Cout, Cin, k), P, dev)
             db, dgam, dbeta = (_out(sk[j], (Cout,), P, dev) for j in (1, 2, 3))
             nbytes = L_.emb_convblock_workspace_bytes(B, L, cin_pad, Cout, k, code)
             ws = _workspace(dev, nbytes)
-            check(L_.emb_convblock_bwd(ptr(g), int(last), ptr(argmax), ptr(y), ptr(stats), ptr(xin),
-                                       ptr(wflip) if i > 0 else None, drop_p, training, ptr(dx), ptr(dW), ptr(db), ptr(dgam),
+            check(L_.emb_convblock_bwd(ptr(g), int(last), ptr(argmax), None if fused else ptr(y), ptr(stats), ptr(xin),
+                                       ptr(wflip) if i > 0 else None, ptr(wpack), ptr(bias), drop_p, training, ptr(dx), ptr(dW),
+                                       ptr(db), ptr(dgam),
                                        ptr(dbeta), ptr(dy), ptr(ws), ws.numel(), B, L, Cin, cin_pad, Cout, k, code, stream()),
                   "emb_convblock_bwd")
             grads[6 * i:6 * i + 4] = [None if sk[j] is not None else g_ for j, g_ in enumerate((dW, db, dgam, dbeta))]
