@@ -69,13 +69,13 @@ __global__ __launch_bounds__(256 * CH) void first_kernel(const FirstArgs a) {
   const int L = a.L, Lp = a.Lp, C = a.C, SB = a.SB, slot = a.slot, KK = a.KK;
   const int xrows = SB * slot + kXExtra, nks = (KK + 31) / 32;
   // LDS carve
-  constexpr int DYP = BN + 4;                           // fp32 pitch of the pooled-gradient tile (backward)
+  constexpr int DPP = BN + 8, AMP = BN + 8;             // pitches of the pooled-gradient rows (bf16) / argmax rows (bytes)
   T* xs = reinterpret_cast<T*>(arena);                                 // [xrows][8]
-  T* zt = xs + ((xrows * XS + 7) & ~7);                                // F_APPLY: [256][ZP] bf16
-  float* dyt = reinterpret_cast<float*>(zt);                           // backward: [256][DYP] fp32; F_BWGRAD overwrites each
-                                                                       // row's head with its dz in bf16 (pitch 2*DYP)
-  int* rowmap = reinterpret_cast<int*>(MODE >= F_BSUMS ? (char*)(dyt + kFBT * DYP) : (char*)(zt + (MODE == F_APPLY ? kFBT * ZP : 0)));
-  float* red = reinterpret_cast<float*>(rowmap + (MODE == F_BWGRAD ? kFBT : 0));                         // [4][2][BN]
+  T* zt = xs + ((xrows * XS + 7) & ~7);                                // F_APPLY: BN/ReLU output, F_BWGRAD: dz; [256][ZP] bf16
+  T* dp = zt + ((MODE == F_APPLY || MODE == F_BWGRAD) ? kFBT * ZP : 0);   // backward: pooled gradient [SB*Lp][DPP]
+  uint8_t* am = reinterpret_cast<uint8_t*>(dp + (MODE >= F_BSUMS ? SB * Lp * DPP : 0));   // backward: argmax bytes [SB*Lp][AMP]
+  int* rowmap = reinterpret_cast<int*>(am + (MODE >= F_BSUMS ? ((SB * Lp * AMP + 15) & ~15) : 0));   // F_BWGRAD: [256]
+  float* red = reinterpret_cast<float*>(rowmap + (MODE == F_BWGRAD ? kFBT : 0));                      // [4][2][BN]
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, g = lane >> 4, r16 = lane & 15;
   const int grp = wave % CH, rq = wave / CH, gcol = grp * GW;   // channel group, row quarter, first channel of the group
   const int bm = blockIdx.x, tm_begin = bm * a.tpb, tm_end = min(a.tiles_m, tm_begin + a.tpb);
@@ -187,14 +187,36 @@ __global__ __launch_bounds__(256 * CH) void first_kernel(const FirstArgs a) {
   // ---- this thread's pooled-tensor items (window p of sequence slot sq, 8 channels from c0): tile independent, so the
   // index arithmetic (runtime divisions) happens once per kernel, not per tile and phase
   constexpr int NIT = 1024 / NTHR, CV = BN / 8;        // SB * Lp * C / 8 <= 1024 items per tile
-  int it_row[NIT], it_pc[NIT];                         // tile row of the window start | (c0 << 16);  p | sq << 8 | (p % 5) << 16; -1 none
+  int it_row[NIT], it_pc[NIT];                         // tile row of the window start | (c0 << 16);  p | sq << 8; -1 none
   if (MODE != F_STATS) {
 #pragma unroll
     for (int i = 0; i < NIT; ++i) {
       const int it = threadIdx.x + i * NTHR, c0 = (it % CV) * 8, sp = it / CV, sq = sp / Lp, p = sp - sq * Lp;
-      it_row[i] = (sq * L + 2 * p) | (c0 << 16);
-      it_pc[i] = sq < SB ? (p | (sq << 8) | ((p % 5) << 16)) : -1;
+      it_row[i] = MODE == F_APPLY ? ((sq * L + 2 * p) | (c0 << 16)) : (sp | (c0 << 16));   // backward: LDS row sp of dp / am
+      it_pc[i] = sq < SB ? (p | (sq << 8)) : -1;
     }
+  }
+  // backward: the tile's pooled gradient and argmax bytes travel global -> registers -> LDS like the activations
+  bf16x8 gv[MODE >= F_BSUMS ? NIT : 1];
+  uint64_t av[MODE >= F_BSUMS ? NIT : 1];
+  auto issue_g = [&](int tm) {
+    const int b0 = tm * SB, nseq = min(SB, a.B - b0);
+    const T* gsrc = a.dout + (long)b0 * Lp * C;
+    const uint8_t* asrc = a.argmax + (long)b0 * Lp * C;
+#pragma unroll
+    for (int i = 0; i < NIT; ++i) {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) gv[i][e] = (T)0.0f;
+      av[i] = 0x8080808080808080ull;                   // "dropped": matches no window offset
+      if (it_pc[i] >= 0 && (it_pc[i] >> 8) < nseq) {
+        const long off = (long)(threadIdx.x + i * NTHR) * 8;     // items are laid out exactly as [sq][p][c]
+        gv[i] = *reinterpret_cast<const bf16x8*>(gsrc + off);
+        av[i] = *reinterpret_cast<const uint64_t*>(asrc + off);
+      }
+    }
+  };
+  if (MODE >= F_BSUMS) {
+    if (!a.ncl && tm_begin < tm_end) issue_g(tm_begin);
   }
 
   FIRST_T(1);
@@ -206,67 +228,31 @@ __global__ __launch_bounds__(256 * CH) void first_kernel(const FirstArgs a) {
     for (int i = 0; i < kFXV; ++i)
       if (x_pk[i] >= 0) *reinterpret_cast<bf16x8*>(xs + x_lds[i]) = xr[i];
     if (MODE >= F_BSUMS) {
-      // dy tile: every pooled gradient element lands on the row its window's argmax points to.  Windows p and p' share rows
-      // only when |p - p'| < 5, so five barrier-separated phases (p mod 5) make the LDS adds conflict free and their
-      // order fixed (deterministic sums).  ReLU zeros / dropped elements carry bit 6 / 7 in the byte and are skipped.
-      for (int i = threadIdx.x * 4; i < kFBT * DYP; i += NTHR * 4) *reinterpret_cast<float4*>(dyt + i) = make_float4(0.f, 0.f, 0.f, 0.f);
-      bf16x8 gv[NIT];
-      uint64_t av[NIT];
       if (!a.ncl) {
-        const T* gsrc = a.dout + (long)b0 * Lp * C;
-        const uint8_t* asrc = a.argmax + (long)b0 * Lp * C;
 #pragma unroll
-        for (int i = 0; i < NIT; ++i) {
-          if (it_pc[i] >= 0 && ((it_pc[i] >> 8) & 0xFF) < nseq) {
-            const long off = (long)(threadIdx.x + i * NTHR) * 8;     // items are laid out exactly as [sq][p][c]
-            gv[i] = *reinterpret_cast<const bf16x8*>(gsrc + off);
-            av[i] = *reinterpret_cast<const uint64_t*>(asrc + off);
+        for (int i = 0; i < NIT; ++i)
+          if (it_pc[i] >= 0) {
+            const int sp = it_row[i] & 0xFFFF, c0 = it_row[i] >> 16;
+            *reinterpret_cast<bf16x8*>(dp + sp * DPP + c0) = gv[i];
+            *reinterpret_cast<uint64_t*>(am + sp * AMP + c0) = av[i];
           }
-        }
-      }
-      __syncthreads();                                  // zero fill complete
-      FIRST_T(2 + (tm - tm_begin) * 8 + 1);
-      if (!a.ncl) {
-        for (int ph = 0; ph < 5; ++ph) {
-#pragma unroll
-          for (int i = 0; i < NIT; ++i) {
-            if (it_pc[i] >= 0 && ((it_pc[i] >> 8) & 0xFF) < nseq && (it_pc[i] >> 16) == ph) {
-              float* rowbase = dyt + (it_row[i] & 0xFFFF) * DYP + (it_row[i] >> 16);
-              // read-modify-write, branch free: all eight reads in flight before the first write; an element without a
-              // target (ReLU zero / dropped) rewrites its own window-start cell, which nobody else touches in this phase
-              int off[8];
-              float old[8];
-#pragma unroll
-              for (int e = 0; e < 8; ++e) {
-                const int code = (int)((av[i] >> (8 * e)) & 0xFF);
-                off[e] = (code < 0x40 ? code * DYP : 0) + e;
-                old[e] = rowbase[off[e]];
-              }
-#pragma unroll
-              for (int e = 0; e < 8; ++e) {
-                const int code = (int)((av[i] >> (8 * e)) & 0xFF);
-                rowbase[off[e]] = old[e] + (code < 0x40 ? (float)gv[i][e] * a.keep_scale : 0.0f);
-              }
-            }
-          }
-          __syncthreads();
-        }
-      } else {                                          // dout[b][c][p] (single-block stack): element-wise, same phases
-        for (int ph = 0; ph < 5; ++ph) {
-          for (int i = threadIdx.x; i < nseq * C * Lp; i += NTHR) {
-            const int sq = i / (C * Lp), rem = i - sq * C * Lp, c = rem / Lp, p = rem - c * Lp;
-            if (p % 5 == ph) {
-              const int code = a.argmax[((long)(b0 + sq) * Lp + p) * C + c];
-              if (code < 0x40) dyt[(sq * L + 2 * p + code) * DYP + c] += (float)a.dout[((long)(b0 + sq) * C + c) * Lp + p] * a.keep_scale;
-            }
-          }
-          __syncthreads();
+      } else {                                          // dout[b][c][p] (single-block stack): element-wise transpose
+        for (int i = threadIdx.x; i < SB * C * Lp; i += NTHR) {
+          const int sq = i / (C * Lp), rem = i - sq * C * Lp, c = rem / Lp, p = rem - c * Lp;
+          const bool v = sq < nseq;
+          dp[(sq * Lp + p) * DPP + c] = v ? a.dout[((long)(b0 + sq) * C + c) * Lp + p] : (T)0.0f;
+          am[(sq * Lp + p) * AMP + c] = v ? a.argmax[((long)(b0 + sq) * Lp + p) * C + c] : (uint8_t)0x80;
         }
       }
     }
     __syncthreads();
     FIRST_T(2 + (tm - tm_begin) * 8 + 2);
-    if (tm + 1 < tm_end) issue_x(tm + 1);
+    if (tm + 1 < tm_end) {
+      issue_x(tm + 1);
+      if (MODE >= F_BSUMS) {
+        if (!a.ncl) issue_g(tm + 1);
+      }
+    }
 
 #pragma unroll
     for (int h = 0; h < 2; ++h) {                      // two row tiles at a time (accumulator registers)
@@ -330,15 +316,32 @@ __global__ __launch_bounds__(256 * CH) void first_kernel(const FirstArgs a) {
             *reinterpret_cast<bf16x4*>(dst) = o;
           }
         } else {
-          // this lane's CPL channels of its row of the pooled-gradient tile
+          // dy[ch] of this lane's row t: the windows containing t are p = t/2 - k, k = 0..4, and window p selected row t iff
+          // its argmax byte equals t - 2p = (t & 1) + 2k (ReLU zeros / dropped elements carry bit 6 / 7: never equal)
           float dy[CPL];
-          {
-            const float* src = dyt + row * DYP + gcol + g * CPL;
 #pragma unroll
-            for (int qv = 0; qv < CPL / 4; ++qv) {
-              const float4 v = *reinterpret_cast<const float4*>(src + qv * 4);
-              dy[qv * 4 + 0] = v.x; dy[qv * 4 + 1] = v.y; dy[qv * 4 + 2] = v.z; dy[qv * 4 + 3] = v.w;
+          for (int e = 0; e < CPL; ++e) dy[e] = 0.0f;
+          {
+            const int tt = rv ? t : 0, par = tt & 1, pb = tt >> 1;
+#pragma unroll
+            for (int k = 0; k < 5; ++k) {
+              const int pw = pb - k;
+              const bool pv = rv && pw >= 0 && pw < Lp;
+              const uint32_t want = pv ? (uint32_t)(par + 2 * k) : 0xFFu;
+              const int sp = sq * Lp + (pv ? pw : 0);
+              const T* gp = dp + sp * DPP + gcol + g * CPL;
+              const uint8_t* ap = am + sp * AMP + gcol + g * CPL;
+#pragma unroll
+              for (int qv = 0; qv < CPL / 4; ++qv) {
+                const bf16x4 gq = *reinterpret_cast<const bf16x4*>(gp + qv * 4);
+                const uint32_t aq = *reinterpret_cast<const uint32_t*>(ap + qv * 4);
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+                  dy[qv * 4 + e] += ((aq >> (8 * e)) & 0xFFu) == want ? (float)gq[e] : 0.0f;
+              }
             }
+#pragma unroll
+            for (int e = 0; e < CPL; ++e) dy[e] *= a.keep_scale;
           }
           if (MODE == F_BSUMS) {
 #pragma unroll
@@ -358,8 +361,7 @@ __global__ __launch_bounds__(256 * CH) void first_kernel(const FirstArgs a) {
                 const float dz = k0[mt][r] * dy[mt * 4 + r] + k1[mt][r] * acc[mt][j][r] + k2[mt][r];
                 ov[mt * 4 + r] = (T)(rv ? dz : 0.0f);
               }
-            // in place: the four lane-groups of a row are lanes of THIS wave and have all read their dy above
-            T* dst = zt + row * (2 * DYP) + gcol + g * CPL;
+            T* dst = zt + row * ZP + gcol + g * CPL;
             if (CPL >= 8) {
 #pragma unroll
               for (int qv = 0; qv < CPL / 8; ++qv) {
@@ -453,10 +455,10 @@ __global__ __launch_bounds__(256 * CH) void first_kernel(const FirstArgs a) {
         bf16x8 af[MIW], bfw[NIW];
 #pragma unroll
         for (int mi = 0; mi < MIW; ++mi) {
-          const T* a0 = zt + ra * (2 * DYP) + mi * 16 + 4 * p4;
+          const T* a0 = zt + ra * ZP + mi * 16 + 4 * p4;
           union { struct { s16x4 lo, hi; } s; bf16x8 v; } u;
           u.s.lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(a0));
-          u.s.hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(a0 + 4 * (2 * DYP)));
+          u.s.hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(a0 + 4 * ZP));
           af[mi] = u.v;
         }
         const int x0 = rowmap[ra] * XS, x1 = rowmap[ra + 4] * XS;
@@ -547,10 +549,10 @@ static bool first_geom(int B, int L, int cin_pad, int Cout, int k, FirstGeom* gm
 }
 
 static size_t first_lds(int mode, const FirstGeom& gm, int Lp, int C) {
-  const int BN = C, ZP = BN + 8, DYP = BN + 4;
+  const int BN = C, ZP = BN + 8, DPP = BN + 8, AMP = BN + 8;
   size_t bytes = (((size_t)gm.xrows * 8 + 7) & ~(size_t)7) * 2;
-  if (mode == F_APPLY) bytes += (size_t)kFBT * ZP * 2;
-  if (mode >= F_BSUMS) bytes += (size_t)kFBT * DYP * 4;
+  if (mode == F_APPLY || mode == F_BWGRAD) bytes += (size_t)kFBT * ZP * 2;
+  if (mode >= F_BSUMS) bytes += (size_t)gm.SB * Lp * DPP * 2 + (((size_t)gm.SB * Lp * AMP + 15) & ~(size_t)15);
   if (mode == F_BWGRAD) bytes += kFBT * sizeof(int);
   bytes += (size_t)4 * 2 * BN * sizeof(float);
   return (bytes + 15) & ~(size_t)15;
