@@ -287,6 +287,8 @@ extern "C" int emb_counter_add(uint64_t* counter, uint64_t inc, emb_stream_t str
 // table travels BY VALUE in the kernel argument (baked into a hipGraph node at capture time, rebuilt for free
 // on every eager call) and is first copied to LDS, so that it is never indexed dynamically in the kernarg
 // segment (see the hipcc note in embrace_bwd.hip).
+#include <mutex>
+#include <unordered_map>
 namespace emb {
 constexpr int kMaxTensors = 40;
 constexpr int kChunk = 1024;   // elements per block
@@ -296,6 +298,8 @@ template <typename P> struct MultiArgs {
   P* m[kMaxTensors];
   P* v[kMaxTensors];
   __bf16* sh[kMaxTensors];
+  __bf16* flip[kMaxTensors];     // conv weights: tap-flipped packed copy (nullable)
+  int pk_k[kMaxTensors], pk_cin[kMaxTensors], pk_cinpad[kMaxTensors], pk_cout[kMaxTensors];   // pk_k == 0: plain shadow
   long long n[kMaxTensors];
   long long blk_end[kMaxTensors];
   long long count;
@@ -368,8 +372,32 @@ __global__ __launch_bounds__(256) void multi_opt_kernel(const MultiArgs<P> args,
       m[i] = mi; v[i] = vi;
     }
     p[i] = pi;
-    if (sh) sh[i] = (__bf16)(float)pi;
+    if (sh) {
+      const int k = a.pk_k[t];
+      if (k == 0) {
+        sh[i] = (__bf16)(float)pi;
+      } else {   // registered conv weight W[o][ci][j]: keep its packed images current (see emb_conv_pack_register)
+        const int cin = a.pk_cin[t], ii = (int)i, o = ii / (cin * k), rem = ii - o * cin * k, ci = rem / k, j = rem - ci * k;
+        sh[((long)o * k + j) * a.pk_cinpad[t] + ci] = (__bf16)(float)pi;
+        if (a.flip[t]) a.flip[t][((long)ci * k + (k - 1 - j)) * a.pk_cout[t] + o] = (__bf16)(float)pi;
+      }
+    }
   }
+}
+
+// ---- packed conv-weight registry: parameters whose packed bf16 images the optimizer launch maintains
+struct PackDesc {
+  void* wpack;
+  void* wflip;
+  int Cout, Cin, cin_pad, k;
+};
+static std::unordered_map<const void*, PackDesc>& pack_table() {
+  static std::unordered_map<const void*, PackDesc> t;
+  return t;
+}
+static std::mutex& pack_mutex() {
+  static std::mutex m;
+  return m;
 }
 
 template <typename P, int OPT>
@@ -386,6 +414,17 @@ static int multi_launch(void* const* params, const void* const* grads, void* con
       a.m[i] = s1 ? (P*)s1[j] : nullptr;
       a.v[i] = s2 ? (P*)s2[j] : nullptr;
       a.sh[i] = shadows ? (__bf16*)shadows[j] : nullptr;
+      a.flip[i] = nullptr;
+      a.pk_k[i] = a.pk_cin[i] = a.pk_cinpad[i] = a.pk_cout[i] = 0;
+      if (sizeof(P) == 4 && i < cnt) {
+        std::lock_guard<std::mutex> lk(pack_mutex());
+        auto it = pack_table().find(params[j]);
+        if (it != pack_table().end() && (int64_t)it->second.Cout * it->second.Cin * it->second.k == sizes[j]) {
+          a.sh[i] = (__bf16*)it->second.wpack;
+          a.flip[i] = (__bf16*)it->second.wflip;
+          a.pk_k[i] = it->second.k; a.pk_cin[i] = it->second.Cin; a.pk_cinpad[i] = it->second.cin_pad; a.pk_cout[i] = it->second.Cout;
+        }
+      }
       a.n[i] = i < cnt ? sizes[j] : 0;
       if (i < cnt) blocks += (sizes[j] + kChunk - 1) / kChunk;
       a.blk_end[i] = blocks;
@@ -398,6 +437,19 @@ static int multi_launch(void* const* params, const void* const* grads, void* con
   return EMB_OK;
 }
 }  // namespace emb
+
+extern "C" int emb_conv_pack_register(const void* W, void* wpack, void* wflip, int Cout, int Cin, int cin_pad, int k) {
+  EMB_CHECK_ARG(W && wpack && Cout > 0 && Cin > 0 && cin_pad >= Cin && k > 0, "emb_conv_pack_register: bad argument");
+  std::lock_guard<std::mutex> lk(emb::pack_mutex());
+  emb::pack_table()[W] = emb::PackDesc{wpack, wflip, Cout, Cin, cin_pad, k};
+  return EMB_OK;
+}
+
+extern "C" int emb_conv_pack_unregister(const void* W) {
+  std::lock_guard<std::mutex> lk(emb::pack_mutex());
+  emb::pack_table().erase(W);
+  return EMB_OK;
+}
 
 extern "C" int emb_adam_step_multi(void* const* params, const void* const* grads, void* const* exp_avg, void* const* exp_avg_sq,
                                    void* const* bf16_shadows, const int64_t* sizes, int ntensors, double lr, double beta1,

@@ -73,6 +73,57 @@ def shadow_lookup(w):
     return ent[2]
 
 
+# Packed images of conv weights (tap-major wpack, tap-flipped wflip; csrc/convblock.hip) cached per Parameter object like
+# the shadows above.  For bf16 compute on fp32 masters the pair is registered with the library, whose fused optimizer
+# launches then keep it current in place (emb_conv_pack_register): no pack launch per step.  Any other update of the
+# parameter bumps its version counter and triggers a re-pack here.
+_PACKS = {}
+
+
+_PACK_FINALIZERS = set()          # ids of parameters that already carry the clean-up finalizer
+
+
+def _pack_drop(key, w_ptr):
+    _PACKS.pop(key, None)
+    _PACK_FINALIZERS.discard(key)
+    try:
+        _lib.lib().emb_conv_pack_unregister(w_ptr)
+    except Exception:
+        pass
+
+
+def conv_packed(w, T, cin_pad, need_flip):
+    """(wpack [Cout][k*cin_pad], wflip [cin_pad][k*Cout] or None) of conv weight `w` [Cout][Cin][k] in dtype T."""
+    Cout, Cin, k = w.shape
+    ent = _PACKS.get(id(w))
+    if ent is not None and ent[0]() is not w:
+        _pack_drop(id(w), ent[1][1])
+        ent = None
+    key = (w._version, w.data_ptr(), tuple(w.shape), T, cin_pad)
+    registered = T == torch.bfloat16 and w.dtype == torch.float32    # only then does the optimizer launch maintain the images;
+    if registered and ent is not None and ent[1] == key and (ent[3] is not None or not need_flip):   # else: re-pack every call
+        return ent[2], ent[3]
+    if ent is not None:
+        _lib.lib().emb_conv_pack_unregister(ent[1][1])
+    dev = w.device
+    reuse = ent is not None and ent[2].dtype == T and ent[2].shape == (Cout, k * cin_pad) and ent[2].device == dev
+    wpack = ent[2] if reuse else torch.empty(Cout, k * cin_pad, dtype=T, device=dev)
+    wflip = None
+    if need_flip:
+        wflip = ent[3] if (reuse and ent[3] is not None) else torch.empty(cin_pad, k * Cout, dtype=T, device=dev)
+    wd = w.detach()
+    wd = wd if wd.is_contiguous() else wd.contiguous()
+    check(_lib.lib().emb_conv_pack_weight(ptr(wd), ptr(wpack), ptr(wflip), Cout, Cin, cin_pad, k, DTYPE_CODE[T], stream()),
+          "emb_conv_pack_weight")
+    if T == torch.bfloat16 and w.dtype == torch.float32 and wd.data_ptr() == w.data_ptr():
+        check(_lib.lib().emb_conv_pack_register(w.data_ptr(), ptr(wpack), ptr(wflip), Cout, Cin, cin_pad, k), "emb_conv_pack_register")
+        if id(w) not in _PACK_FINALIZERS:           # the table entry must not outlive the parameter's storage
+            _PACK_FINALIZERS.add(id(w))
+            weakref.finalize(w, _pack_drop, id(w), w.data_ptr())
+    _PACKS[id(w)] = (weakref.ref(w), key, wpack, wflip)
+    return wpack, wflip
+
+
 # Optional gradient sinks: when a parameter has a registered sink (dist.FlatGrads: a view into one flat
 # buffer that also is its .grad), the backward kernels write the parameter gradient straight into it and
 # autograd is told "no gradient" -- no per-parameter accumulate / copy kernels, and the data-parallel
@@ -438,10 +489,7 @@ class _ConvStackFn(torch.autograd.Function):
                 if t.dtype != P:
                     raise TypeError(f"conv stack parameters must be {P} for compute dtype {T}")
             Cout, Cin, k = w.shape
-            wpack = torch.empty(Cout, k * cin_pad, dtype=T, device=dev)
-            wflip = torch.empty(cin_pad, k * Cout, dtype=T, device=dev) if i > 0 else None
-            check(L_.emb_conv_pack_weight(ptr(w.detach().contiguous()), ptr(wpack), ptr(wflip), Cout, Cin, cin_pad, k, code,
-                                          stream()), "emb_conv_pack_weight")
+            wpack, wflip = conv_packed(w, T, cin_pad, need_flip=i > 0)
             Lp = pool_out_len(L)
             last = i == n_layers - 1
             # first block with a few-channel input: recomputed in every pass instead of stored (csrc/conv_first.hip)

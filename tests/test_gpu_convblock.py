@@ -137,3 +137,39 @@ def test_full_model_hip_prenets_match_stock_operators(ea):
                      m.CNN.CNN_model[1].running_var.clone()))
     for a, b in zip(*outs):
         assert (a - b).abs().max().item() < 1e-9 * max(1.0, b.abs().max().item())
+
+
+def test_fused_optimizer_keeps_packed_conv_weights_current(ea):
+    """bf16 compute on fp32 masters: the packed images are written by the optimizer launch (emb_conv_pack_register),
+    no pack kernel per step -- after a step they must equal a fresh pack of the updated parameters."""
+    from embracenet_amd import optim
+    F = ea.functional
+    L, ptr, st = ea._lib.lib(), ea._lib.ptr, ea._lib.stream
+    torch.manual_seed(3)
+    blocks = [Blk(f"cb/opt/{i}", ci, co, k, torch.float32) for i, (ci, co, k) in enumerate([(4, 32, 11), (32, 16, 5)])]
+    for b in blocks:
+        b.conv.to(DEV); b.bn.to(DEV)
+    layers = [dict(conv=b.conv, bn=b.bn, drop_p=0.0, layer_id=4 + i) for i, b in enumerate(blocks)]
+    params = [p for b in blocks for p in (b.conv.weight, b.conv.bias, b.bn.weight, b.bn.bias)]
+    opt = optim.Adam(params, lr=1e-2)
+    x = torch.from_numpy(dg.onehot_sequence("cb/opt/x", 8)).to(DEV)
+    for _ in range(3):
+        opt.zero_grad()
+        y = F.conv_stack(x, layers, True, rng=F.RngState(seed=1), compute_dtype=torch.bfloat16)
+        y.float().square().mean().backward()
+        opt.step()
+    torch.cuda.synchronize()
+    cin_pad = 8
+    for i, b in enumerate(blocks):
+        w = b.conv.weight
+        Cout, Cin, k = w.shape
+        wpack, wflip = F.conv_packed(w, torch.bfloat16, cin_pad, need_flip=i > 0)      # cache hit: optimizer-maintained buffers
+        ref_pack = torch.empty_like(wpack)
+        ref_flip = torch.empty_like(wflip) if wflip is not None else None
+        ea._lib.check(L.emb_conv_pack_weight(ptr(w.detach()), ptr(ref_pack), ptr(ref_flip), Cout, Cin, cin_pad, k,
+                                             ea._lib.DTYPE_CODE[torch.bfloat16], st()), "pack")
+        torch.cuda.synchronize()
+        assert torch.equal(wpack.view(torch.int16), ref_pack.view(torch.int16)), f"block {i}: wpack stale"
+        if wflip is not None:
+            assert torch.equal(wflip.view(torch.int16), ref_flip.view(torch.int16)), f"block {i}: wflip stale"
+        cin_pad = Cout
