@@ -254,9 +254,12 @@ __global__ __launch_bounds__(256 * CH) void first_kernel(const FirstArgs a) {
       }
     }
 
-#pragma unroll
-    for (int h = 0; h < 2; ++h) {                      // two row tiles at a time (accumulator registers)
-      __builtin_amdgcn_sched_barrier(0);               // keep the two halves apart: interleaving them doubles the live registers
+#pragma unroll 1
+    for (int h = 0; h < 2; ++h) {                      // two row tiles at a time (accumulator registers); a real loop: the
+                                                       // unrolled form interleaves the halves and doubles the live registers
+      const int xrow_h[2] = {h ? xrow[2] : xrow[0], h ? xrow[3] : xrow[1]};
+      const int sq_h[2] = {h ? row_sq[2] : row_sq[0], h ? row_sq[3] : row_sq[1]};
+      const int t_h[2] = {h ? row_t[2] : row_t[0], h ? row_t[3] : row_t[1]};
       typename Mm::AccV acc[MT][2];
 #pragma unroll
       for (int mt = 0; mt < MT; ++mt)
@@ -270,7 +273,7 @@ __global__ __launch_bounds__(256 * CH) void first_kernel(const FirstArgs a) {
           bf16x8 bf[2];
 #pragma unroll
           for (int j = 0; j < 2; ++j)                  // cin == 8: k-step ks, lane-group g reads tap 4*ks + g: one LDS row
-            bf[j] = *reinterpret_cast<const bf16x8*>(xs + (xrow[2 * h + j] + 4 * ks + g) * XS);
+            bf[j] = *reinterpret_cast<const bf16x8*>(xs + (xrow_h[j] + 4 * ks + g) * XS);
 #pragma unroll
           for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
@@ -279,7 +282,7 @@ __global__ __launch_bounds__(256 * CH) void first_kernel(const FirstArgs a) {
       }
 #pragma unroll
       for (int j = 0; j < 2; ++j) {
-        const int nt = 2 * h + j, sq = row_sq[nt], t = row_t[nt];
+        const int nt = 2 * h + j, sq = sq_h[j], t = t_h[j];
         const bool rv = t >= 0 && sq < nseq;
         const int row = rq * 64 + nt * 16 + r16;
         if (MODE == F_STATS) {
