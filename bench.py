@@ -179,6 +179,9 @@ def main():
     ap.add_argument("--cpu-baseline-seconds", type=float, default=15.0)
     ap.add_argument("--no-extras", action="store_true", help="skip roofline and cpu_baseline legs")
     ap.add_argument("--roofline-only", action="store_true", help="only time the isolated kernels (used under rocprofv3 --pmc)")
+    ap.add_argument("--split-graph", action="store_true", help="N>1: keep the all-reduce outside the captured graphs")
+    ap.add_argument("--force-collectives", action="store_true",
+                    help="run the N>1 code path (flat gradient buffer, all-reduce in the step) with a single rank")
     args = ap.parse_args()
 
     import embracenet_amd as ea
@@ -193,6 +196,10 @@ def main():
     if args.dtype:
         wl["dtype"] = args.dtype
     B, Fin = wl["B"], wl["F"]
+    dist_path = world > 1 or args.force_collectives      # flat gradient buffer + all-reduce inside the step
+    if args.force_collectives and world == 1 and not torch.distributed.is_initialized():
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        torch.distributed.init_process_group(args.backend or "nccl", init_method="tcp://127.0.0.1:29537", rank=0, world_size=1)
 
     if args.roofline_only:
         kern, dims = kernel_roofline(ea, wl, device)
@@ -217,14 +224,14 @@ def main():
     # data-parallel reduction is a single in-place RCCL all-reduce.  Two trailing slots carry the NEXT step's
     # local (positives, rows): the global class counts a step needs before its loss are thus
     # reduced one step ahead inside the gradient collective (labels are known when a batch is staged).
-    flat = D.FlatGrads(model.parameters(), extra=2) if world > 1 else None
-    local_counts = F.count_labels(y).to(torch.float32) if world > 1 else None
+    flat = D.FlatGrads(model.parameters(), extra=2) if dist_path else None
+    local_counts = F.count_labels(y).to(torch.float32) if dist_path else None
 
     def fwd_bwd():
         if flat is None:
             opt.zero_grad(set_to_none=True)
         out = model([x1, x2], is_training=True)
-        _, dlogits = F.weighted_ce_with_grad(out, y, class_counts=counts, global_counts=world > 1, confusion=conf_slot,
+        _, dlogits = F.weighted_ce_with_grad(out, y, class_counts=counts, global_counts=dist_path, confusion=conf_slot,
                                              loss_out=loss_slot, ticks=ticks)
         out.backward(dlogits)
 
@@ -233,7 +240,7 @@ def main():
         flat.allreduce()
         counts.copy_(flat.extra.round().to(torch.int64))
 
-    if world > 1:                                         # counts of the very first step
+    if dist_path:                                         # counts of the very first step
         F.count_labels(y, out=counts)
         D.allreduce_counts(counts)
 
@@ -253,18 +260,39 @@ def main():
 
     use_graph = not args.eager
     if use_graph:
-        if world == 1:
+        graph_mode = "one hipGraph per step"
+        step = None
+        if not dist_path:
             g_all = torch.cuda.CUDAGraph()
             with torch.cuda.graph(g_all):
                 fwd_bwd()
                 opt.step()
             step = g_all.replay
-        else:                                             # collectives stay outside the captured regions
+        elif not args.split_graph and torch.distributed.get_backend() == "nccl":
+            # RCCL collectives are capturable: the whole step, all-reduce included, replays as ONE graph (no host
+            # round trip between backward, collective and optimizer).  Any failure falls back to the split form.
+            try:
+                g_all = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g_all):
+                    fwd_bwd()
+                    reduce_grads()
+                    opt.step()
+                g_all.replay()
+                torch.cuda.synchronize()
+                step = g_all.replay
+                graph_mode = "one hipGraph per step, RCCL all-reduce captured"
+            except Exception as e:                        # noqa: BLE001 - report and fall back
+                if rank == 0:
+                    print(f"[bench] single-graph capture with the collective failed ({type(e).__name__}: {e}); "
+                          "using two graphs around an eager all-reduce", file=sys.stderr, flush=True)
+                step = None
+        if step is None:                                  # collectives stay outside the captured regions
             g_fb, g_opt = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
             with torch.cuda.graph(g_fb):
                 fwd_bwd()
             with torch.cuda.graph(g_opt, pool=g_fb.pool()):
                 opt.step()
+            graph_mode = "two hipGraphs around an eager all-reduce"
 
             def step():
                 g_fb.replay()
@@ -272,6 +300,7 @@ def main():
                 g_opt.replay()
     else:
         step = eager_step
+        graph_mode = "eager"
 
     for _ in range(args.warmup):
         step()
@@ -301,7 +330,7 @@ def main():
             "config": {"workload": wl["name"], "per_gpu_batch": B, "global_batch": B * world,
                        "parallelism": f"dp{world} (batch-sharded, RCCL all-reduce of gradients)" if world > 1 else "single GPU",
                        "step": "zero_grad+fwd+weighted CE+bwd" + ("+allreduce" if world > 1 else "") + "+fused Adam",
-                       "graph": bool(use_graph), "rng": "philox (device-side modality dropout and selection)",
+                       "graph": bool(use_graph), "graph_mode": graph_mode, "rng": "philox (device-side modality dropout and selection)",
                        "final_loss": final_loss},
         }
         if world == 1 and not args.no_extras:
@@ -319,7 +348,7 @@ def main():
             result["speedup_vs_cpu_baseline"] = value / result["cpu_baseline"]["value"]
         print(json.dumps(result), flush=True)
     D.barrier()
-    if world > 1:
+    if torch.distributed.is_initialized():
         torch.distributed.destroy_process_group()
 
 

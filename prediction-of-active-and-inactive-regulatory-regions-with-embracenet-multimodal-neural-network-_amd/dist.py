@@ -114,7 +114,7 @@ class FlatGrads:
         self.extra = self.flat[off:off + extra] if extra else None
 
     def allreduce(self):
-        if world_size() > 1:
+        if dist.is_initialized():          # also with a single rank (bench.py --force-collectives rehearses the capture)
             dist.all_reduce(self.flat, op=dist.ReduceOp.SUM)
 
 
