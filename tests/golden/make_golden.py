@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Generate the golden fixtures G1-G9 by importing the reference on CPU.
+"""Generate the golden fixtures G1-G10 by importing the reference on CPU.
 
 Runs ONLY in the build container (needs /root/reference).  The fixtures it writes under
 tests/golden/ are data (inputs are regenerated from oracle/datagen.py by name; outputs are
@@ -470,7 +470,51 @@ def g9():
     save("G9_fit_trajectory", arrays, meta)
 
 
+# =========================================================================== G10
+def g10():
+    """Inference twin: the reference's EmbraceNetMultimodal_NoTrain rebuilt from a checkpoint in the
+    harness format ({'model_state_dict', 'model_params'}, Kfold_CV_Multimodal :639-641) and called the way
+    visual.Compare_Models_Result.get_model_predictions does (:266-293): .double(), eval, one region per call."""
+    from BIOINF_tesi.models.EmbraceNetMultimodal_NoTrain import EmbraceNetMultimodal_NoTrain
+    arrays, meta = {}, {"cases": []}
+    cwd = os.getcwd()
+    for cfg_name, N, seed in (("small", 12, 3101), ("post2", 8, 3102)):
+        tag = f"g10/{cfg_name}"
+        model, oracle, trial, hp, F_in = build_ref_model(cfg_name, tag)
+        cell, task, n_iter = "A549", "active_E_vs_inactive_E", 1
+        x1, x2, _ = batch(f"{tag}/N{N}", N, F_in)
+        with tempfile.TemporaryDirectory() as td:
+            os.chdir(td)
+            try:
+                torch.save({"model_state_dict": model.state_dict(), "model_params": dict(hp)},
+                           f"{cell}_EmbraceNetMultimodal_{task}_{n_iter}_test_.pt")
+                with contextlib.redirect_stderr(io.StringIO()):
+                    twin = EmbraceNetMultimodal_NoTrain(cell, task, n_iter, F_in, device="cpu")
+                state = torch.load(f"{cell}_EmbraceNetMultimodal_{task}_{n_iter}_test_.pt", map_location="cpu")
+                twin.load_state_dict(state["model_state_dict"])
+                twin.double().to("cpu")
+                twin.eval()
+                import warnings
+                with torch.no_grad(), warnings.catch_warnings():
+                    warnings.simplefilter("ignore")
+                    torch.manual_seed(seed)
+                    per_sample = torch.stack([twin([x1[i:i + 1], x2[i:i + 1]]) for i in range(N)])     # [N, 2]
+                    torch.manual_seed(seed + 1)
+                    batched = twin([x1, x2])                                                          # [2N]
+            finally:
+                os.chdir(cwd)
+        assert per_sample.shape == (N, 2) and batched.shape == (2 * N,)
+        assert torch.allclose(per_sample.sum(1), torch.ones(N, dtype=torch.float64), atol=1e-12)
+        key = f"{cfg_name}_N{N}"
+        arrays[key + "_per_sample"] = per_sample.numpy()
+        arrays[key + "_batched"] = batched.numpy()
+        meta["cases"].append(dict(key=key, cfg=cfg_name, tag=tag, N=N, seed=seed, cell_line=cell, task=task, n_iter=n_iter,
+                                  state_keys=list(model.state_dict().keys())))
+        print("G10", key, "p1 range", float(per_sample[:, 1].min()), float(per_sample[:, 1].max()))
+    save("G10_inference_twin", arrays, meta)
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g5", "g6", "g7", "g8", "g9"]
+    which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g5", "g6", "g7", "g8", "g9", "g10"]
     for w in which:
         globals()[w]()

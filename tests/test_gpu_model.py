@@ -171,3 +171,37 @@ def test_philox_training_step_bf16_runs_and_learns(ea):
         opt.step()
         losses.append(loss.item())
     assert np.isfinite(losses).all() and np.mean(losses[-5:]) < np.mean(losses[:5]) - 0.02, losses
+
+
+@pytest.mark.parametrize("i", range(2))
+def test_g10_inference_twin_matches_reference(ea, i, tmp_path):
+    """Row f3: EmbraceNetMultimodal_NoTrain rebuilt from a harness-format checkpoint reproduces the reference's twin --
+    per-region calls as visual.Compare_Models_Result makes them, and one batched call (fp64, host RNG replay)."""
+    g = Golden("G10_inference_twin")
+    case = g.meta["cases"][i]
+    src, trial, hp, F_in = build(ea, case["cfg"], case["tag"])
+    N = case["N"]
+    ck = tmp_path / f"{case['cell_line']}_EmbraceNetMultimodal_{case['task']}_{case['n_iter']}_test_.pt"
+    torch.save({"model_state_dict": {k: v.cpu() for k, v in src.state_dict().items()}, "model_params": dict(hp)}, ck)
+    assert list(src.state_dict().keys()) == case["state_keys"]
+    twin = ea.EmbraceNetMultimodal_NoTrain(case["cell_line"], case["task"], case["n_iter"], F_in, device=DEV,
+                                           checkpoint_dir=str(tmp_path))
+    state = torch.load(ck, map_location=DEV, weights_only=True)
+    twin.load_state_dict(state["model_state_dict"])
+    twin.double().to(DEV)
+    twin.set_rng("host")
+    twin.eval()
+    assert all(not p.requires_grad for p in twin.FFNN.parameters()) and all(not p.requires_grad for p in twin.CNN.parameters())
+    x1, x2, _ = batch(f"{case['tag']}/N{N}", N, F_in, torch.float64)
+    with torch.no_grad():
+        torch.manual_seed(case["seed"])
+        per = torch.stack([twin([x1[j:j + 1], x2[j:j + 1]]) for j in range(N)])
+        torch.manual_seed(case["seed"] + 1)
+        batched = twin([x1, x2])
+    assert per.shape == (N, 2) and batched.shape == (2 * N,)
+    assert np.abs(per.cpu().numpy() - g[case["key"] + "_per_sample"]).max() < 1e-9
+    assert np.abs(batched.cpu().numpy() - g[case["key"] + "_batched"]).max() < 1e-9
+    # the batched entry point returns the positive-class column
+    torch.manual_seed(case["seed"] + 1)
+    p1 = twin.predict_proba(x1.cpu(), x2.cpu(), batch_size=N)
+    assert np.abs(p1.cpu().numpy() - g[case["key"] + "_batched"].reshape(N, 2)[:, 1]).max() < 1e-9

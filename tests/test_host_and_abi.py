@@ -104,3 +104,22 @@ def test_step_table_roundtrip(ea):
         ls.fill_(0.5 * k); cs.copy_(torch.tensor([k, k + 1, k + 2, 10]))
     losses, counts = t.fetch()
     assert losses.tolist() == [0.0, 0.5, 1.0] and counts[2].tolist() == [2, 3, 4, 10] and t.n == 0
+
+
+def test_inference_twin_helpers_follow_the_reference():
+    """utils.py:360-375 / :178-202 restated in inference.py (host logic of row f3)."""
+    import importlib.util
+    import os
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    import sys
+    sys.path.insert(0, root)
+    import embracenet_amd as ea
+    from oracle.configs import CONFIGS
+    hp, _ = CONFIGS["cfg1"]
+    single = ea.inference.get_single_model_params(hp)
+    assert single["FFNN"]["n_layers"] == hp["FFNN_n_layers"] and single["CNN"]["kernel_size_l0"] == hp["CNN_kernel_size_l0"]
+    assert "embracement_size" not in single["CNN"] and "n_units_l0" in single["FFNN"]
+    # two blocks of (conv k=15 same padding, maxpool 10/2) on 256 positions: 124 -> 58 positions x 32 channels
+    assert ea.inference.output_size_from_model_params(single["CNN"]) == 58 * hp["CNN_out_channels_l1"] == 1856
+    assert ea.inference.checkpoint_name("A549", "t", 3) == "A549_EmbraceNetMultimodal_t_3_test_.pt"
+    assert ea.inference.checkpoint_name("A549", "t", 3, augmentation=True) == "A549_EmbraceNetMultimodal_augmentation_t_3_test_.pt"

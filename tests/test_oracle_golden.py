@@ -137,6 +137,24 @@ def test_g2_full_model_oracle():
         assert np.array_equal(m.last["idx"].numpy(), unpack_idx(g[case["key"] + "_idx"], case["B"], m.c))
 
 
+def test_g10_inference_twin_oracle():
+    """Row f3: softmax over the oracle's eval logits == the reference's EmbraceNetMultimodal_NoTrain, per region and batched."""
+    g = Golden("G10_inference_twin")
+    for case in g.meta["cases"]:
+        m, hp, F_in = _oracle_model(case["cfg"], case["tag"])
+        N = case["N"]
+        x1, x2, _ = model_batch(f"{case['tag']}/N{N}", N, F_in)
+        x1, x2 = torch.from_numpy(x1), torch.from_numpy(x2)
+        m.eval()
+        with torch.no_grad():
+            torch.manual_seed(case["seed"])
+            per = torch.stack([torch.softmax(m([x1[j:j + 1], x2[j:j + 1]]), dim=1).reshape(-1) for j in range(N)])
+            torch.manual_seed(case["seed"] + 1)
+            batched = torch.softmax(m([x1, x2]), dim=1).reshape(-1)
+        assert np.abs(per.numpy() - g[case["key"] + "_per_sample"]).max() < 1e-12
+        assert np.abs(batched.numpy() - g[case["key"] + "_batched"]).max() < 1e-12
+
+
 def test_g3_train_step_oracle():
     g = Golden("G3_model_train_step")
     for case in g.meta["cases"]:
