@@ -179,6 +179,8 @@ def main():
     ap.add_argument("--cpu-baseline-seconds", type=float, default=15.0)
     ap.add_argument("--no-extras", action="store_true", help="skip roofline and cpu_baseline legs")
     ap.add_argument("--roofline-only", action="store_true", help="only time the isolated kernels (used under rocprofv3 --pmc)")
+    ap.add_argument("--packed-input", action="store_true",
+                    help="stage the DNA windows as uint8 base codes (SURVEY 8 row f4) instead of the loader's [B,4,256] floats")
     ap.add_argument("--split-graph", action="store_true", help="N>1: keep the all-reduce outside the captured graphs")
     ap.add_argument("--force-collectives", action="store_true",
                     help="run the N>1 code path (flat gradient buffer, all-reduce in the step) with a single rank")
@@ -213,7 +215,7 @@ def main():
     opt = optim.Adam(model.parameters(), lr=1e-3, weight_decay=1e-3)
     x1, x2, y = synth_batch(B, Fin, wl["pos"], device, 100 + rank)
     in_dt = model.compute_dtype or next(model.parameters()).dtype   # inputs staged in the compute dtype
-    x1, x2 = x1.to(in_dt), x2.to(in_dt)
+    x1, x2 = x1.to(in_dt), (ea.functional.pack_onehot(x2) if args.packed_input else x2.to(in_dt))
     counts = torch.zeros(2, dtype=torch.int64, device=device)
     table = ea.metrics.StepTable(1, device)
     loss_slot, conf_slot = table.slot()
@@ -330,7 +332,8 @@ def main():
             "config": {"workload": wl["name"], "per_gpu_batch": B, "global_batch": B * world,
                        "parallelism": f"dp{world} (batch-sharded, RCCL all-reduce of gradients)" if world > 1 else "single GPU",
                        "step": "zero_grad+fwd+weighted CE+bwd" + ("+allreduce" if world > 1 else "") + "+fused Adam",
-                       "graph": bool(use_graph), "graph_mode": graph_mode, "rng": "philox (device-side modality dropout and selection)",
+                       "graph": bool(use_graph), "graph_mode": graph_mode,
+                       "sequence_input": "uint8 base codes [B,256]" if args.packed_input else "one-hot [B,4,256] (loader format)", "rng": "philox (device-side modality dropout and selection)",
                        "final_loss": final_loss},
         }
         if world == 1 and not args.no_extras:

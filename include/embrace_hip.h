@@ -194,7 +194,11 @@ int emb_nadam_step_multi(void* const* params, const void* const* grads, void* co
  *                         than to store: the caller then passes y = NULL to emb_convblock_fwd and y = dy = dx = NULL
  *                         plus wpack and bias to emb_convblock_bwd, and the [B][L][Cout] tensors never exist
  *                         (forward: statistics pass + fused conv/BN/ReLU/pool pass; backward: reduction pass + fused
- *                         dz/weight-gradient pass).  The argmax byte then also carries bit 6 = pooled output is 0. */
+ *                         dz/weight-gradient pass).  The argmax byte then also carries bit 6 = pooled output is 0.
+ *                         In that mode the input may be staged as BASE CODES: x_codes != 0 -> x is
+ *                         uint8[B][L] with 0-3 = the hot channel of the one-hot column (dataprepare.py:398-412 order) and
+ *                         any other value = an all-zero column; the one-hot row is formed in LDS, the [B][4][L] float
+ *                         tensor and its layout conversion never exist (8x less input traffic).  x_codes = 0 otherwise. */
 int64_t emb_convblock_workspace_bytes(int B, int L, int cin_pad, int Cout, int k, int dtype);
 int emb_ncl_to_nlc(const void* x, int src_dtype, void* out, int dst_dtype, int B, int C, int L, int Cpad,
                    emb_stream_t stream);
@@ -210,13 +214,13 @@ int emb_convblock_fwd(const void* x, const void* wpack, const void* bias, const 
                       void* running_mean, void* running_var, int training, double momentum, double eps,
                       float dropout_p, uint64_t seed, uint64_t step_val, const uint64_t* step_dev, int64_t row0,
                       int layer_id, void* y, void* stats, void* out, uint8_t* argmax, int out_ncl, void* workspace,
-                      int64_t workspace_bytes, int64_t* num_batches_tracked, int B, int L, int cin_pad, int Cout,
-                      int k, int dtype, emb_stream_t stream);
+                      int64_t workspace_bytes, int64_t* num_batches_tracked, int x_codes, int B, int L, int cin_pad,
+                      int Cout, int k, int dtype, emb_stream_t stream);
 int emb_convblock_bwd(const void* dout, int dout_ncl, const uint8_t* argmax, const void* y, const void* stats,
                       const void* x, const void* wflip, const void* wpack, const void* bias, float dropout_p,
                       int training, void* dx, void* dW, void* dbias, void* dgamma, void* dbeta, void* dy,
-                      void* workspace, int64_t workspace_bytes, int B, int L, int Cin, int cin_pad, int Cout, int k,
-                      int dtype, emb_stream_t stream);
+                      void* workspace, int64_t workspace_bytes, int x_codes, int B, int L, int Cin, int cin_pad,
+                      int Cout, int k, int dtype, emb_stream_t stream);
 int emb_convblock_needs_y(int B, int L, int cin_pad, int Cout, int k, int dtype);
 
 /* helpers: dtype conversion (fp32/fp64 master -> bf16 shadow etc.) and a device step counter */

@@ -7,15 +7,16 @@ namespace emb {
 
 int conv_first_supported(int dtype, int B, int L, int cin_pad, int Cout, int k);   // 1 when the fused kernels apply
 int conv_first_blocks(int B, int L, int cin_pad, int Cout, int k);                 // workgroups = partial rows = wgrad slices
+// x_codes == 0: x is [B][L][8] bf16 channels-last; else x is [B][L] uint8 base codes (0-3), one-hot expanded while staging.
 // each returns EMB_OK, a negative error, or 1 when the shapes do not qualify
-int conv_first_stats(const void* x, const void* w, const void* bias, void* partial, int* rows, int B, int L, int Cout, int k,
+int conv_first_stats(const void* x, int x_codes, const void* w, const void* bias, void* partial, int* rows, int B, int L, int Cout, int k,
                      hipStream_t s);
-int conv_first_apply(const void* x, const void* w, const void* bias, const void* stats, void* out, uint8_t* argmax, int out_ncl,
+int conv_first_apply(const void* x, int x_codes, const void* w, const void* bias, const void* stats, void* out, uint8_t* argmax, int out_ncl,
                      float drop_p, uint64_t seed, uint64_t step_val, const uint64_t* step_dev, int64_t row0, int layer_id, int B, int L,
                      int Cout, int k, hipStream_t s);
-int conv_first_bwd_sums(const void* dout, int dout_ncl, const uint8_t* argmax, const void* x, const void* w, const void* bias,
+int conv_first_bwd_sums(const void* dout, int dout_ncl, const uint8_t* argmax, const void* x, int x_codes, const void* w, const void* bias,
                         const void* stats, float keep_scale, void* bpart, int* rows, int B, int L, int Cout, int k, hipStream_t s);
-int conv_first_bwd_wgrad(const void* dout, int dout_ncl, const uint8_t* argmax, const void* x, const void* w, const void* bias,
+int conv_first_bwd_wgrad(const void* dout, int dout_ncl, const uint8_t* argmax, const void* x, int x_codes, const void* w, const void* bias,
                          const void* stats, const void* coef, float keep_scale, int training, void* slab, int* slices, int B, int L,
                          int Cout, int k, hipStream_t s);
 

@@ -35,7 +35,10 @@ constexpr int kFBT = 256, kFXV = 2;            // rows per workgroup tile; activ
 enum { F_STATS = 0, F_APPLY = 1, F_BSUMS = 2, F_BWGRAD = 3 };
 
 struct FirstArgs {
-  const __bf16* x;          // [B][L][8] channels-last, zero-padded channels
+  const void* x;            // x_codes == 0: [B][L][8] bf16 channels-last, zero-padded channels
+                            // x_codes != 0: [B][L] uint8 base codes (0-3 = A,C,G,T channel; anything else = all-zero column),
+                            //               expanded to the one-hot row while staging
+  int x_codes;
   const __bf16* w;          // [C][KK] packed weights, KK = k*8
   const float* bias;        // [C]
   const float* stats;       // [4][C] mean, invstd, scale, shift (not read by F_STATS)
@@ -93,17 +96,31 @@ __global__ __launch_bounds__(256 * CH) void first_kernel(const FirstArgs a) {
   bf16x8 xr[kFXV];
   auto issue_x = [&](int tm) {
     const int b0 = tm * SB;
-    const T* xb = a.x + (long)b0 * L * XS;
+    if (!a.x_codes) {
+      const T* xb = reinterpret_cast<const T*>(a.x) + (long)b0 * L * XS;
 #pragma unroll
-    for (int i = 0; i < kFXV; ++i) {
-      bf16x8 v;
+      for (int i = 0; i < kFXV; ++i) {
+        bf16x8 v;
 #pragma unroll
-      for (int e = 0; e < 8; ++e) v[e] = (T)0.0f;
-      if (x_pk[i] >= 0) {
-        const int s = x_pk[i] >> 16, tt = (x_pk[i] & 0xffff) - a.pad;
-        if (b0 + s < a.B && tt >= 0 && tt < L) v = *reinterpret_cast<const bf16x8*>(xb + x_glb[i]);
+        for (int e = 0; e < 8; ++e) v[e] = (T)0.0f;
+        if (x_pk[i] >= 0) {
+          const int s = x_pk[i] >> 16, tt = (x_pk[i] & 0xffff) - a.pad;
+          if (b0 + s < a.B && tt >= 0 && tt < L) v = *reinterpret_cast<const bf16x8*>(xb + x_glb[i]);
+        }
+        xr[i] = v;
       }
-      xr[i] = v;
+    } else {   // one byte per position; the one-hot row is formed when the tile is written to LDS
+      const uint8_t* cb = reinterpret_cast<const uint8_t*>(a.x) + (long)b0 * L;
+#pragma unroll
+      for (int i = 0; i < kFXV; ++i) {
+        uint32_t code = 0xFFu;
+        if (x_pk[i] >= 0) {
+          const int s = x_pk[i] >> 16, tt = (x_pk[i] & 0xffff) - a.pad;
+          if (b0 + s < a.B && tt >= 0 && tt < L) code = cb[(long)s * L + tt];
+        }
+        uint4 w = make_uint4(code, 0u, 0u, 0u);
+        xr[i] = __builtin_bit_cast(bf16x8, w);
+      }
     }
   };
   if (tm_begin < tm_end) issue_x(tm_begin);
@@ -226,7 +243,16 @@ __global__ __launch_bounds__(256 * CH) void first_kernel(const FirstArgs a) {
     FIRST_T(2 + (tm - tm_begin) * 8 + 0);
 #pragma unroll
     for (int i = 0; i < kFXV; ++i)
-      if (x_pk[i] >= 0) *reinterpret_cast<bf16x8*>(xs + x_lds[i]) = xr[i];
+      if (x_pk[i] >= 0) {
+        bf16x8 v = xr[i];
+        if (a.x_codes) {   // bf16 1.0 = 0x3F80 in the selected channel (two channels per 32-bit word)
+          const uint32_t code = __builtin_bit_cast(uint4, xr[i]).x;
+          const uint4 w = make_uint4(code == 0 ? 0x00003F80u : code == 1 ? 0x3F800000u : 0u,
+                                     code == 2 ? 0x00003F80u : code == 3 ? 0x3F800000u : 0u, 0u, 0u);
+          v = __builtin_bit_cast(bf16x8, w);
+        }
+        *reinterpret_cast<bf16x8*>(xs + x_lds[i]) = v;
+      }
     if (MODE >= F_BSUMS) {
       if (!a.ncl) {
 #pragma unroll
@@ -597,51 +623,54 @@ static void first_fill(FirstArgs& a, const FirstGeom& gm, int B, int L, int Cout
   a.SB = gm.SB; a.slot = gm.slot; a.tiles_m = gm.tiles_m; a.tpb = gm.tpb;
 }
 
-int conv_first_stats(const void* x, const void* w, const void* bias, void* partial, int* rows, int B, int L, int Cout, int k,
-                     hipStream_t s) {
+int conv_first_stats(const void* x, int x_codes, const void* w, const void* bias, void* partial, int* rows, int B, int L, int Cout,
+                     int k, hipStream_t s) {
   FirstGeom gm;
   if (!first_geom(B, L, 8, Cout, k, &gm)) return 1;
   FirstArgs a{};
   first_fill(a, gm, B, L, Cout, k);
-  a.x = (const __bf16*)x; a.w = (const __bf16*)w; a.bias = (const float*)bias; a.partial = (float*)partial;
+  a.x = x; a.x_codes = x_codes; a.w = (const __bf16*)w; a.bias = (const float*)bias; a.partial = (float*)partial;
   *rows = gm.nblk;
   return first_launch<F_STATS>(a, gm, s);
 }
 
-int conv_first_apply(const void* x, const void* w, const void* bias, const void* stats, void* out, uint8_t* argmax, int out_ncl,
+int conv_first_apply(const void* x, int x_codes, const void* w, const void* bias, const void* stats, void* out, uint8_t* argmax,
+                     int out_ncl,
                      float drop_p, uint64_t seed, uint64_t step_val, const uint64_t* step_dev, int64_t row0, int layer_id, int B, int L,
                      int Cout, int k, hipStream_t s) {
   FirstGeom gm;
   if (!first_geom(B, L, 8, Cout, k, &gm)) return 1;
   FirstArgs a{};
   first_fill(a, gm, B, L, Cout, k);
-  a.x = (const __bf16*)x; a.w = (const __bf16*)w; a.bias = (const float*)bias; a.stats = (const float*)stats;
+  a.x = x; a.x_codes = x_codes; a.w = (const __bf16*)w; a.bias = (const float*)bias; a.stats = (const float*)stats;
   a.out = (__bf16*)out; a.argmax = argmax; a.ncl = out_ncl; a.drop_p = drop_p; a.seed = seed; a.step_val = step_val;
   a.step_dev = step_dev; a.grow0 = row0; a.layer_id = layer_id;
   return first_launch<F_APPLY>(a, gm, s);
 }
 
-int conv_first_bwd_sums(const void* dout, int dout_ncl, const uint8_t* argmax, const void* x, const void* w, const void* bias,
+int conv_first_bwd_sums(const void* dout, int dout_ncl, const uint8_t* argmax, const void* x, int x_codes, const void* w,
+                        const void* bias,
                         const void* stats, float keep_scale, void* bpart, int* rows, int B, int L, int Cout, int k, hipStream_t s) {
   FirstGeom gm;
   if (!first_geom(B, L, 8, Cout, k, &gm)) return 1;
   FirstArgs a{};
   first_fill(a, gm, B, L, Cout, k);
-  a.x = (const __bf16*)x; a.w = (const __bf16*)w; a.bias = (const float*)bias; a.stats = (const float*)stats;
+  a.x = x; a.x_codes = x_codes; a.w = (const __bf16*)w; a.bias = (const float*)bias; a.stats = (const float*)stats;
   a.dout = (const __bf16*)dout; a.ncl = dout_ncl; a.argmax = const_cast<uint8_t*>(argmax); a.keep_scale = keep_scale;
   a.partial = (float*)bpart;
   *rows = gm.nblk;
   return first_launch<F_BSUMS>(a, gm, s);
 }
 
-int conv_first_bwd_wgrad(const void* dout, int dout_ncl, const uint8_t* argmax, const void* x, const void* w, const void* bias,
+int conv_first_bwd_wgrad(const void* dout, int dout_ncl, const uint8_t* argmax, const void* x, int x_codes, const void* w,
+                         const void* bias,
                          const void* stats, const void* coef, float keep_scale, int training, void* slab, int* slices, int B, int L,
                          int Cout, int k, hipStream_t s) {
   FirstGeom gm;
   if (!first_geom(B, L, 8, Cout, k, &gm)) return 1;
   FirstArgs a{};
   first_fill(a, gm, B, L, Cout, k);
-  a.x = (const __bf16*)x; a.w = (const __bf16*)w; a.bias = (const float*)bias; a.stats = (const float*)stats;
+  a.x = x; a.x_codes = x_codes; a.w = (const __bf16*)w; a.bias = (const float*)bias; a.stats = (const float*)stats;
   a.dout = (const __bf16*)dout; a.ncl = dout_ncl; a.argmax = const_cast<uint8_t*>(argmax); a.keep_scale = keep_scale;
   a.coef = (const float*)coef; a.training = training; a.slab = (float*)slab;
   *slices = gm.nblk;

@@ -564,7 +564,8 @@ template <typename T>
 static int convblock_fwd(const void* x, const void* wpack, const void* bias, const void* gamma, const void* beta, void* rmean,
                          void* rvar, int training, double momentum, double eps, float drop_p, uint64_t seed, uint64_t step_val,
                          const uint64_t* step_dev, int64_t row0, int layer_id, void* y, void* stats, void* out, uint8_t* argmax,
-                         int out_ncl, void* ws, int64_t ws_bytes, void* nbt, int B, int L, int cin_pad, int Cout, int k, hipStream_t s) {
+                         int out_ncl, void* ws, int64_t ws_bytes, void* nbt, int x_codes, int B, int L, int cin_pad, int Cout, int k,
+                         hipStream_t s) {
   using P = typename AccOf<T>::type;
   constexpr int VEC = Elem<T>::VEC;
   const ConvWs w = conv_workspace<T>(B, L, cin_pad, Cout, k);
@@ -572,18 +573,19 @@ static int convblock_fwd(const void* x, const void* wpack, const void* bias, con
   EMB_CHECK_ARG(cin_pad % VEC == 0 && Cout % VEC == 0, "emb_convblock_fwd: channels must be multiples of %d", VEC);
   const int R = B * L, KK = k * cin_pad, pad = (k - 1) / 2, Lp = (L - kPoolK) / kPoolS + 1;
   EMB_CHECK_ARG(Lp >= 1, "emb_convblock_fwd: sequence too short for the pooling window");
+  EMB_CHECK_ARG(!x_codes || y == nullptr, "emb_convblock_fwd: base-code input (x_codes) needs the fused first block (y == NULL)");
   if (y == nullptr) {   // first block, nothing stored: statistics pass + fused apply pass, both recompute the convolution
     EMB_CHECK_ARG(conv_first_supported(dtype_code<T>(), B, L, cin_pad, Cout, k),
                   "emb_convblock_fwd: y may only be NULL when emb_convblock_needs_y() returns 0");
     int rows = 0;
     if (training) {
-      const int rc0 = conv_first_stats(x, wpack, bias, ws, &rows, B, L, Cout, k, s);
+      const int rc0 = conv_first_stats(x, x_codes, wpack, bias, ws, &rows, B, L, Cout, k, s);
       if (rc0 != EMB_OK) return rc0 == 1 ? EMB_ERR_ARG : rc0;
     }
     bn_finalize_kernel<P><<<Cout, 256, 0, s>>>((const P*)ws, rows, Cout, (double)R, (const P*)gamma, (const P*)beta, (P*)rmean,
                                              (P*)rvar, training, momentum, eps, (P*)stats, (long long*)nbt);
     EMB_CHECK_LAUNCH();
-    const int rc1 = conv_first_apply(x, wpack, bias, stats, out, argmax, out_ncl, drop_p, seed, step_val, step_dev, row0, layer_id, B, L,
+    const int rc1 = conv_first_apply(x, x_codes, wpack, bias, stats, out, argmax, out_ncl, drop_p, seed, step_val, step_dev, row0, layer_id, B, L,
                                      Cout, k, s);
     return rc1 == 1 ? EMB_ERR_ARG : rc1;
   }
@@ -611,8 +613,8 @@ static int convblock_fwd(const void* x, const void* wpack, const void* bias, con
 template <typename T>
 static int convblock_bwd(const void* dout, int dout_ncl, const uint8_t* argmax, const void* y, const void* stats, const void* x,
                          const void* wflip, const void* wpack, const void* bias, float drop_p, int training, void* dx, void* dW,
-                         void* dbias, void* dgamma, void* dbeta, void* dy, void* ws, int64_t ws_bytes, int B, int L, int Cin,
-                         int cin_pad, int Cout, int k, hipStream_t s) {
+                         void* dbias, void* dgamma, void* dbeta, void* dy, void* ws, int64_t ws_bytes, int x_codes, int B, int L,
+                         int Cin, int cin_pad, int Cout, int k, hipStream_t s) {
   using P = typename AccOf<T>::type;
   using CW = typename ConvCfg<T>::W;
   constexpr int VEC = Elem<T>::VEC;
@@ -624,6 +626,7 @@ static int convblock_bwd(const void* dout, int dout_ncl, const uint8_t* argmax, 
   P* bpart = (P*)base;
   P* coef = (P*)(base + w.bwd_partial);
   P* slab = (P*)(base + w.bwd_partial + w.coef);
+  EMB_CHECK_ARG(!x_codes || y == nullptr, "emb_convblock_bwd: base-code input (x_codes) needs the fused first block (y == NULL)");
   if (y == nullptr) {   // first block without stored activations (conv_first.hip)
     EMB_CHECK_ARG(conv_first_supported(dtype_code<T>(), B, L, cin_pad, Cout, k) && dx == nullptr && wpack && bias,
                   "emb_convblock_bwd: y == NULL needs the fused first block (emb_convblock_needs_y() == 0), wpack, bias and no dx");
@@ -631,11 +634,11 @@ static int convblock_bwd(const void* dout, int dout_ncl, const uint8_t* argmax, 
     EMB_CHECK_ARG((size_t)nb * 2 * Cout * sizeof(P) <= w.bwd_partial && (size_t)nb * Cout * (KK + 1) * sizeof(P) <= w.slab,
                   "emb_convblock_bwd: workspace layout too small for the fused first block");
     int rows = 0, S = 0;
-    int rc = conv_first_bwd_sums(dout, dout_ncl, argmax, x, wpack, bias, stats, keep_scale, bpart, &rows, B, L, Cout, k, s);
+    int rc = conv_first_bwd_sums(dout, dout_ncl, argmax, x, x_codes, wpack, bias, stats, keep_scale, bpart, &rows, B, L, Cout, k, s);
     if (rc != EMB_OK) return rc == 1 ? EMB_ERR_ARG : rc;
     bn_bwd_finalize_kernel<P><<<Cout, 256, 0, s>>>(bpart, rows, Cout, (double)R, (P*)dgamma, (P*)dbeta, coef);
     EMB_CHECK_LAUNCH();
-    rc = conv_first_bwd_wgrad(dout, dout_ncl, argmax, x, wpack, bias, stats, coef, keep_scale, training, slab, &S, B, L, Cout, k, s);
+    rc = conv_first_bwd_wgrad(dout, dout_ncl, argmax, x, x_codes, wpack, bias, stats, coef, keep_scale, training, slab, &S, B, L, Cout, k, s);
     if (rc != EMB_OK) return rc == 1 ? EMB_ERR_ARG : rc;
     const long n = (long)Cout * (KK + 1);
     conv_wgrad_reduce_kernel<P><<<(int)((n + 15) / 16), 256, 0, s>>>(slab, S, Cout, Cin, cin_pad, k, (P*)dW, (P*)dbias);
@@ -755,17 +758,17 @@ extern "C" int emb_convblock_fwd(const void* x, const void* wpack, const void* b
                                  void* running_mean, void* running_var, int training, double momentum, double eps,
                                  float dropout_p, uint64_t seed, uint64_t step_val, const uint64_t* step_dev, int64_t row0,
                                  int layer_id, void* y, void* stats, void* out, uint8_t* argmax, int out_ncl, void* workspace,
-                                 int64_t workspace_bytes, int64_t* num_batches_tracked, int B, int L, int cin_pad, int Cout, int k,
-                                 int dtype, emb_stream_t stream) {
+                                 int64_t workspace_bytes, int64_t* num_batches_tracked, int x_codes, int B, int L, int cin_pad,
+                                 int Cout, int k, int dtype, emb_stream_t stream) {
   EMB_CHECK_ARG(x && wpack && bias && gamma && beta && running_mean && running_var && stats && out && argmax && workspace,
                 "emb_convblock_fwd: null pointer");
   EMB_CHECK_ARG(B > 0 && L > 0 && cin_pad > 0 && Cout > 0 && k > 0 && (k & 1), "emb_convblock_fwd: bad dims");
   EMB_CHECK_ARG(dropout_p >= 0.f && dropout_p < 1.f, "emb_convblock_fwd: dropout_p must be in [0,1)");
   hipStream_t s = (hipStream_t)stream;
   switch (dtype) {
-    case EMB_F32: return convblock_fwd<float>(x, wpack, bias, gamma, beta, running_mean, running_var, training, momentum, eps, dropout_p, seed, step_val, step_dev, row0, layer_id, y, stats, out, argmax, out_ncl, workspace, workspace_bytes, num_batches_tracked, B, L, cin_pad, Cout, k, s);
-    case EMB_BF16: return convblock_fwd<__bf16>(x, wpack, bias, gamma, beta, running_mean, running_var, training, momentum, eps, dropout_p, seed, step_val, step_dev, row0, layer_id, y, stats, out, argmax, out_ncl, workspace, workspace_bytes, num_batches_tracked, B, L, cin_pad, Cout, k, s);
-    case EMB_F64: return convblock_fwd<double>(x, wpack, bias, gamma, beta, running_mean, running_var, training, momentum, eps, dropout_p, seed, step_val, step_dev, row0, layer_id, y, stats, out, argmax, out_ncl, workspace, workspace_bytes, num_batches_tracked, B, L, cin_pad, Cout, k, s);
+    case EMB_F32: return convblock_fwd<float>(x, wpack, bias, gamma, beta, running_mean, running_var, training, momentum, eps, dropout_p, seed, step_val, step_dev, row0, layer_id, y, stats, out, argmax, out_ncl, workspace, workspace_bytes, num_batches_tracked, x_codes, B, L, cin_pad, Cout, k, s);
+    case EMB_BF16: return convblock_fwd<__bf16>(x, wpack, bias, gamma, beta, running_mean, running_var, training, momentum, eps, dropout_p, seed, step_val, step_dev, row0, layer_id, y, stats, out, argmax, out_ncl, workspace, workspace_bytes, num_batches_tracked, x_codes, B, L, cin_pad, Cout, k, s);
+    case EMB_F64: return convblock_fwd<double>(x, wpack, bias, gamma, beta, running_mean, running_var, training, momentum, eps, dropout_p, seed, step_val, step_dev, row0, layer_id, y, stats, out, argmax, out_ncl, workspace, workspace_bytes, num_batches_tracked, x_codes, B, L, cin_pad, Cout, k, s);
   }
   set_error("emb_convblock_fwd: unsupported dtype %d", dtype);
   return EMB_ERR_DTYPE;
@@ -778,17 +781,17 @@ extern "C" int emb_convblock_needs_y(int B, int L, int cin_pad, int Cout, int k,
 extern "C" int emb_convblock_bwd(const void* dout, int dout_ncl, const uint8_t* argmax, const void* y, const void* stats,
                                  const void* x, const void* wflip, const void* wpack, const void* bias, float dropout_p,
                                  int training, void* dx, void* dW, void* dbias, void* dgamma, void* dbeta, void* dy, void* workspace,
-                                 int64_t workspace_bytes, int B, int L, int Cin, int cin_pad, int Cout, int k, int dtype,
-                                 emb_stream_t stream) {
+                                 int64_t workspace_bytes, int x_codes, int B, int L, int Cin, int cin_pad, int Cout, int k,
+                                 int dtype, emb_stream_t stream) {
   EMB_CHECK_ARG(dout && argmax && stats && x && dW && dbias && dgamma && dbeta && workspace && (y == nullptr || dy != nullptr),
                 "emb_convblock_bwd: null pointer");
   EMB_CHECK_ARG(dx == nullptr || wflip != nullptr, "emb_convblock_bwd: wflip is required when dx is requested");
   EMB_CHECK_ARG(B > 0 && L > 0 && Cin > 0 && cin_pad >= Cin && Cout > 0 && k > 0 && (k & 1), "emb_convblock_bwd: bad dims");
   hipStream_t s = (hipStream_t)stream;
   switch (dtype) {
-    case EMB_F32: return convblock_bwd<float>(dout, dout_ncl, argmax, y, stats, x, wflip, wpack, bias, dropout_p, training, dx, dW, dbias, dgamma, dbeta, dy, workspace, workspace_bytes, B, L, Cin, cin_pad, Cout, k, s);
-    case EMB_BF16: return convblock_bwd<__bf16>(dout, dout_ncl, argmax, y, stats, x, wflip, wpack, bias, dropout_p, training, dx, dW, dbias, dgamma, dbeta, dy, workspace, workspace_bytes, B, L, Cin, cin_pad, Cout, k, s);
-    case EMB_F64: return convblock_bwd<double>(dout, dout_ncl, argmax, y, stats, x, wflip, wpack, bias, dropout_p, training, dx, dW, dbias, dgamma, dbeta, dy, workspace, workspace_bytes, B, L, Cin, cin_pad, Cout, k, s);
+    case EMB_F32: return convblock_bwd<float>(dout, dout_ncl, argmax, y, stats, x, wflip, wpack, bias, dropout_p, training, dx, dW, dbias, dgamma, dbeta, dy, workspace, workspace_bytes, x_codes, B, L, Cin, cin_pad, Cout, k, s);
+    case EMB_BF16: return convblock_bwd<__bf16>(dout, dout_ncl, argmax, y, stats, x, wflip, wpack, bias, dropout_p, training, dx, dW, dbias, dgamma, dbeta, dy, workspace, workspace_bytes, x_codes, B, L, Cin, cin_pad, Cout, k, s);
+    case EMB_F64: return convblock_bwd<double>(dout, dout_ncl, argmax, y, stats, x, wflip, wpack, bias, dropout_p, training, dx, dW, dbias, dgamma, dbeta, dy, workspace, workspace_bytes, x_codes, B, L, Cin, cin_pad, Cout, k, s);
   }
   set_error("emb_convblock_bwd: unsupported dtype %d", dtype);
   return EMB_ERR_DTYPE;

@@ -474,12 +474,25 @@ class _ConvStackFn(torch.autograd.Function):
         L_ = _lib.lib()
         P = PARAM_DTYPE[T]
         dev, code = x.device, DTYPE_CODE[T]
-        B, C0, L = x.shape
+        codes_in = x.dtype == torch.uint8 and x.dim() == 2          # base codes [B][L] (pack_onehot), SURVEY 8 row f4
+        if codes_in:
+            (B, L), C0 = x.shape, 4
+        else:
+            B, C0, L = x.shape
         x = x if x.is_contiguous() else x.contiguous()
         vec = _vec(T)
         cin_pad = -(-C0 // vec) * vec
-        cur = torch.empty(B, L, cin_pad, dtype=T, device=dev)
-        check(L_.emb_ncl_to_nlc(ptr(x), DTYPE_CODE[x.dtype], ptr(cur), code, B, C0, L, cin_pad, stream()), "emb_ncl_to_nlc")
+        x_codes = 0
+        if codes_in:
+            Cout0, _, k0 = tensors[0].shape
+            if L_.emb_convblock_needs_y(B, L, cin_pad, Cout0, k0, code) == 0:
+                cur, x_codes = x, 1                                  # the fused first block expands the codes while staging
+            else:                                                    # other configurations: expand here, channels-last
+                cur = torch.zeros(B, L, cin_pad, dtype=T, device=dev)
+                cur[:, :, :4] = (x.unsqueeze(-1) == torch.arange(4, device=dev, dtype=torch.uint8)).to(T)
+        else:
+            cur = torch.empty(B, L, cin_pad, dtype=T, device=dev)
+            check(L_.emb_ncl_to_nlc(ptr(x), DTYPE_CODE[x.dtype], ptr(cur), code, B, C0, L, cin_pad, stream()), "emb_ncl_to_nlc")
         saved, shapes = [], []
         n_layers = len(meta)
         for i, m in enumerate(meta):
@@ -503,19 +516,19 @@ class _ConvStackFn(torch.autograd.Function):
             check(L_.emb_convblock_fwd(ptr(cur), ptr(wpack), ptr(b.detach()), ptr(g.detach()), ptr(beta.detach()), ptr(rmean),
                                        ptr(rvar), int(training), float(m["momentum"]), float(m["eps"]), float(m["drop_p"]),
                                        rng.seed, rng.step_val, ptr(rng.step_dev), rng.row0, int(m["layer_id"]), ptr(y),
-                                       ptr(stats), ptr(out), ptr(argmax), int(last), ptr(ws), ws.numel(), ptr(nbt), B, L,
-                                       cin_pad, Cout, k, code, stream()), "emb_convblock_fwd")
+                                       ptr(stats), ptr(out), ptr(argmax), int(last), ptr(ws), ws.numel(), ptr(nbt),
+                                       x_codes if i == 0 else 0, B, L, cin_pad, Cout, k, code, stream()), "emb_convblock_fwd")
             saved += [cur, y if y is not None else stats, stats, argmax, wflip if wflip is not None else stats, wpack, b.detach()]
             shapes.append((L, Cin, cin_pad, Cout, k, float(m["drop_p"]), fused))
             cur, L, cin_pad = out, Lp, Cout
         ctx.save_for_backward(*saved)
-        ctx.cfg = (T, int(training), B, shapes)
+        ctx.cfg = (T, int(training), B, shapes, x_codes)
         ctx.sinks = tuple(grad_sink(tensors[6 * i + j], P) for i in range(n_layers) for j in range(4))
         return cur.reshape(B, -1)
 
     @staticmethod
     def backward(ctx, dout):
-        T, training, B, shapes = ctx.cfg
+        T, training, B, shapes, x_codes = ctx.cfg
         P = PARAM_DTYPE[T]
         L_ = _lib.lib()
         code = DTYPE_CODE[T]
@@ -537,15 +550,30 @@ class _ConvStackFn(torch.autograd.Function):
             check(L_.emb_convblock_bwd(ptr(g), int(last), ptr(argmax), None if fused else ptr(y), ptr(stats), ptr(xin),
                                        ptr(wflip) if i > 0 else None, ptr(wpack), ptr(bias), drop_p, training, ptr(dx), ptr(dW),
                                        ptr(db), ptr(dgam),
-                                       ptr(dbeta), ptr(dy), ptr(ws), ws.numel(), B, L, Cin, cin_pad, Cout, k, code, stream()),
+                                       ptr(dbeta), ptr(dy), ptr(ws), ws.numel(), x_codes if i == 0 else 0, B, L, Cin, cin_pad, Cout,
+                                       k, code, stream()),
                   "emb_convblock_bwd")
             grads[6 * i:6 * i + 4] = [None if sk[j] is not None else g_ for j, g_ in enumerate((dW, db, dgam, dbeta))]
             g = dx
         return (None, None, None, None, None, *grads)
 
 
+def pack_onehot(x):
+    """[N, 4, L] one-hot windows (the loader's format, dataprepare.py:398-412) -> [N, L] uint8 base codes: the hot channel,
+    4 for an all-zero column.  Done once per data set (host or device); batches then travel and are staged as one byte per
+    position -- `conv_stack` / `CNN_pre` accept the codes directly."""
+    if x.dim() != 3 or x.shape[1] != 4:
+        raise ValueError("pack_onehot expects [N, 4, L] one-hot windows")
+    hot = x != 0
+    if bool((hot.sum(1) > 1).any()) or bool(((x != 0) & (x != 1)).any()):
+        raise ValueError("pack_onehot: input is not one-hot (values other than 0/1 or several channels set)")
+    codes = hot.to(torch.uint8).argmax(1).to(torch.uint8)
+    return torch.where(hot.any(1), codes, torch.full_like(codes, 4)).contiguous()
+
+
 def conv_stack(x, layers, training, rng=None, compute_dtype=None):
-    """layers: list of dicts with conv (nn.Conv1d), bn (nn.BatchNorm1d), drop_p, layer_id."""
+    """layers: list of dicts with conv (nn.Conv1d), bn (nn.BatchNorm1d), drop_p, layer_id.
+    x: [B, C, L] float windows, or [B, L] uint8 base codes from `pack_onehot`."""
     T = compute_dtype or layers[0]["conv"].weight.dtype
     meta, tensors = [], []
     for ly in layers:

@@ -110,7 +110,7 @@ class StepRunner:
         x_1, x_2, target, row0 = self._shard(x_1, x_2, target)
         dt = getattr(model, "compute_dtype", None) or _input_dtype(model)   # cast rides on the host->device copy
         x_1 = x_1.to(dev, dtype=dt, non_blocking=True)
-        x_2 = x_2.to(dev, dtype=dt, non_blocking=True)
+        x_2 = x_2.to(dev, non_blocking=True) if x_2.dtype == torch.uint8 else x_2.to(dev, dtype=dt, non_blocking=True)   # codes stay bytes
         tgt = target.to(dev, non_blocking=True).reshape(-1)
         if hasattr(model, "rng_row0"):
             model.rng_row0 = row0

@@ -178,3 +178,31 @@ def test_fused_optimizer_keeps_packed_conv_weights_current(ea):
         if wflip is not None:
             assert torch.equal(wflip.view(torch.int16), ref_flip.view(torch.int16)), f"block {i}: wflip stale"
         cin_pad = Cout
+
+
+@pytest.mark.parametrize("spec", [[(4, 64, 15), (64, 32, 15)], [(4, 16, 5)], [(4, 96, 11), (96, 64, 5)]],
+                         ids=["fused2", "fused1", "unfused"])
+def test_base_code_input_equals_onehot_input(ea, spec):
+    """Row f4: staging the DNA window as one byte per position (functional.pack_onehot) gives bit-identical outputs and
+    parameter gradients to the [B, 4, L] one-hot tensor (bf16 path; 'unfused' = a first block the fused kernels do not take)."""
+    F = ea.functional
+    B = 21
+    x = dg.onehot_sequence("cb/codes/x", B)
+    x[:, :, 5] = 0                                         # an all-zero column (unknown base)
+    xt = torch.from_numpy(x).to(DEV)
+    codes = F.pack_onehot(xt)
+    assert codes.dtype == torch.uint8 and codes.shape == (B, 256) and int(codes[0, 5]) == 4
+    assert torch.equal(torch.nn.functional.one_hot(codes.long(), 5)[..., :4].permute(0, 2, 1).float(), xt.float())
+    results = []
+    for inp in (xt.float(), codes):
+        blocks = [Blk(f"cb/codes/{i}", ci, co, k, torch.float32) for i, (ci, co, k) in enumerate(spec)]
+        for b in blocks:
+            b.conv.to(DEV); b.bn.to(DEV)
+        layers = [dict(conv=b.conv, bn=b.bn, drop_p=0.0, layer_id=4 + i) for i, b in enumerate(blocks)]
+        out = F.conv_stack(inp, layers, True, rng=F.RngState(seed=5), compute_dtype=torch.bfloat16)
+        out.backward(torch.ones_like(out))
+        results.append((out.detach(), [p.grad.clone() for b in blocks for p in b.params()]))
+    (o1, g1), (o2, g2) = results
+    assert torch.equal(o1, o2)
+    for a, b in zip(g1, g2):
+        assert torch.equal(a, b)
