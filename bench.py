@@ -47,6 +47,11 @@ WORKLOADS["cfg4"] = dict(name="K562 E-vs-P, c=1024, d1=1024, n_post=2, fp32, B=1
                                  EMBRACENET_dropout_l0=0.0, EMBRACENET_n_units_l1=128, EMBRACENET_dropout_l1=0.0,
                                  selection_probabilities_FFNN=0.5))
 
+# BASELINE.json configs[4]: modality dropout p = 0.5 is the model's own training behaviour (EmbraceNetMultimodal.py:178-182),
+# batch 4096, hipGraph-captured step; per-GPU shard of the 8-GPU job = the same model at B = 4096 / N (here: the 1-GPU case)
+WORKLOADS["cfg5"] = dict(WORKLOADS["cfg2"], name="GM12878-like 2-modality EmbraceNet with modality dropout, c=256, B=4096/GPU, bf16",
+                         B=4096)
+
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s (spec); ~6.3 TB/s achievable
 MFMA_PEAK_TFLOPS = {"bfloat16": 2500.0, "float32": 157.3, "float64": 78.6}
 
