@@ -78,8 +78,22 @@ class EmbraceNet(nn.Module, _RngMixin):
         self.last_code = None          # [B,c] uint8 of the latest forward (bit0 = selected modality)
         self._init_rng()
 
+    def _prepare(self, B, dev, availabilities, selection_probabilities, _device_dropout):
+        """Selection cdf of the batch (:63-76) -- independent of the docking inputs, so a caller may run it early / on
+        another stream and hand the result to forward(_prep=...)."""
+        rng = self._rng_state(dev)
+        if selection_probabilities is None:                       # :70-71
+            selection_probabilities = torch.ones(1, 2, dtype=torch.float32, device=dev)
+        p = selection_probabilities.to(device=dev, dtype=torch.float32)
+        if p.dim() == 2 and p.shape[0] not in (1, B):
+            raise ValueError("selection_probabilities must be [B, M] or [M]")
+        avail = None if availabilities is None else availabilities.to(device=dev, dtype=torch.float32)
+        if getattr(self, "_status", None) is None or self._status.device != dev:
+            self._status = torch.zeros(1, dtype=torch.int32, device=dev)       # sticky bits, cleared when read
+        return F_.select_prep(p, avail, B, rng=rng, device_dropout=_device_dropout, status=self._status)
+
     def forward(self, input_list, availabilities=None, selection_probabilities=None, _device_dropout=False,
-                _advance=True):
+                _advance=True, _prep=None):
         assert len(input_list) == len(self.input_size_list)
         if len(input_list) != 2:
             raise NotImplementedError("the gfx950 kernels implement the two-modality EmbraceNet")
@@ -90,16 +104,8 @@ class EmbraceNet(nn.Module, _RngMixin):
         dev = x0.device
         T = self.compute_dtype or self.docking_0.weight.dtype
         rng = self._rng_state(dev)
-
-        if selection_probabilities is None:                       # :70-71
-            selection_probabilities = torch.ones(1, 2, dtype=torch.float32, device=dev)
-        p = selection_probabilities.to(device=dev, dtype=torch.float32)
-        if p.dim() == 2 and p.shape[0] not in (1, B):
-            raise ValueError("selection_probabilities must be [B, M] or [M]")
-        avail = None if availabilities is None else availabilities.to(device=dev, dtype=torch.float32)
-        if getattr(self, "_status", None) is None or self._status.device != dev:
-            self._status = torch.zeros(1, dtype=torch.int32, device=dev)       # sticky bits, cleared when read
-        cdf0, status = F_.select_prep(p, avail, B, rng=rng, device_dropout=_device_dropout, status=self._status)
+        cdf0, status = _prep if _prep is not None else self._prepare(B, dev, availabilities, selection_probabilities,
+                                                                     _device_dropout)
 
         u = None
         if self.rng_mode == "host":                               # replay of torch.multinomial's draws (:84)
@@ -196,24 +202,7 @@ class EmbraceNetMultimodal(nn.Module, _RngMixin):
         self.embracenet.rng_seed, self.embracenet.rng_row0 = self.rng_seed, self.rng_row0
         rng = self.embracenet._rng_state(dev) if x_FFNN.is_cuda else None
         self.FFNN.compute_dtype = self.CNN.compute_dtype = self.compute_dtype
-        if T == torch.bfloat16 and not (self.FFNN.use_hip and self.CNN.use_hip):
-            with torch.autocast("cuda", dtype=torch.bfloat16):          # stock-operator A/B path only
-                h0, h1 = self.FFNN(x_FFNN, rng=rng), self.CNN(x_CNN, rng=rng)
-        elif x_FFNN.is_cuda and getattr(self, "overlap_prenets", True) and not os.environ.get("EMB_NO_OVERLAP"):
-            # the two pre-networks are independent: the (tiny, launch-latency bound) epigenomic MLP runs on a side
-            # stream next to the sequence CNN.  autograd replays each node on its forward stream, so the two
-            # backward chains overlap as well; fork/join by events, which a stream capture records as graph edges
-            cur = torch.cuda.current_stream(dev)
-            side = self._side_stream(dev)
-            side.wait_stream(cur)
-            with torch.cuda.stream(side):
-                h0 = self.FFNN(x_FFNN, rng=rng)
-            h1 = self.CNN(x_CNN, rng=rng)
-            cur.wait_stream(side)
-            h0.record_stream(cur)
-        else:
-            h0, h1 = self.FFNN(x_FFNN, rng=rng), self.CNN(x_CNN, rng=rng)
-        B = h0.shape[0]
+        B = x_FFNN.shape[0]
         device_dropout = False
         if is_training and embracenet_dropout:                              # :178-182
             if self.rng_mode == "host":
@@ -229,8 +218,28 @@ class EmbraceNetMultimodal(nn.Module, _RngMixin):
         if getattr(self, "_sel_key", None) != key:      # device copy made once, not per step (no H2D in a graph)
             self._sel_dev, self._sel_key = sp.detach().to(device=dev, dtype=torch.float32).view(1, 2), key
         p = self._sel_dev
+        prep = None
+        if T == torch.bfloat16 and not (self.FFNN.use_hip and self.CNN.use_hip):
+            with torch.autocast("cuda", dtype=torch.bfloat16):          # stock-operator A/B path only
+                h0, h1 = self.FFNN(x_FFNN, rng=rng), self.CNN(x_CNN, rng=rng)
+        elif x_FFNN.is_cuda and getattr(self, "overlap_prenets", True) and not os.environ.get("EMB_NO_OVERLAP"):
+            # the two pre-networks are independent: the (tiny, launch-latency bound) epigenomic MLP and the selection
+            # cdf run on a side stream next to the sequence CNN.  autograd replays each node on its forward stream, so the
+            # two backward chains overlap as well; fork/join by events, which a stream capture records as graph edges
+            cur = torch.cuda.current_stream(dev)
+            side = self._side_stream(dev)
+            side.wait_stream(cur)
+            with torch.cuda.stream(side):
+                h0 = self.FFNN(x_FFNN, rng=rng)
+                prep = self.embracenet._prepare(B, dev, availabilities, p, device_dropout)
+            h1 = self.CNN(x_CNN, rng=rng)
+            cur.wait_stream(side)
+            h0.record_stream(cur)
+            prep[0].record_stream(cur)
+        else:
+            h0, h1 = self.FFNN(x_FFNN, rng=rng), self.CNN(x_CNN, rng=rng)
         E = self.embracenet([h0, h1], availabilities=availabilities, selection_probabilities=p,
-                            _device_dropout=device_dropout, _advance=False)
+                            _device_dropout=device_dropout, _advance=False, _prep=prep)
         out = self._post_forward(E, rng, T)
         if not getattr(self, "defer_step_tick", False):     # a trainer may fold the tick into its loss kernel (step_counter)
             self.embracenet._advance_step()
