@@ -240,7 +240,10 @@ def main():
         out = model([x1, x2], is_training=True)
         _, dlogits = F.weighted_ce_with_grad(out, y, class_counts=counts, global_counts=dist_path, confusion=conf_slot,
                                              loss_out=loss_slot, ticks=ticks)
+        F.reduce_defer(True)                              # one reduction launch for all weight-gradient slabs of the backward
         out.backward(dlogits)
+        F.reduce_defer(False)
+        F.reduce_flush()
 
     def reduce_grads():
         flat.extra.copy_(local_counts)                    # next batch's labels (synthetic: the same batch)

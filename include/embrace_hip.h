@@ -223,6 +223,14 @@ int emb_convblock_bwd(const void* dout, int dout_ncl, const uint8_t* argmax, con
                       int Cout, int k, int dtype, emb_stream_t stream);
 int emb_convblock_needs_y(int B, int L, int cin_pad, int Cout, int k, int dtype);
 
+/* Slab reductions.  The weight-gradient kernels of emb_embrace_bwd / emb_linear_bwd / emb_mlp_bwd / emb_convblock_bwd write
+ * per-slice partial sums into the caller's workspace and finish with a (deterministic, fixed-order) reduction launch.
+ * After emb_reduce_defer(1) those reductions are only queued; emb_reduce_flush(stream) runs ALL queued ones in one launch.
+ * Until the flush the parameter gradients are incomplete and every workspace handed to a queued call must stay untouched
+ * (give each call site its own workspace).  Process-wide switch, default off (immediate). */
+int emb_reduce_defer(int on);
+int emb_reduce_flush(emb_stream_t stream);
+
 /* helpers: dtype conversion (fp32/fp64 master -> bf16 shadow etc.) and a device step counter */
 int emb_cast(const void* src, int src_dtype, void* dst, int dst_dtype, int64_t n, emb_stream_t stream);
 int emb_counter_add(uint64_t* counter, uint64_t inc, emb_stream_t stream);

@@ -14,6 +14,7 @@
 // pooled gradient by a deterministic gather (no atomics anywhere: results are bitwise reproducible).
 #include "conv_direct.h"
 #include "conv_first.h"
+#include "reduce.h"
 #include "gemm_tile.h"
 
 namespace emb {
@@ -461,34 +462,6 @@ __global__ __launch_bounds__(kThreads) void conv_wgrad_kernel(const typename Cfg
   }
 }
 
-// dW[o][ci][j] (torch Conv1d layout, real channels only) and dbias[o] from the slabs.  Block = 16 slab elements x
-// 16 slice lanes: lane sl sums slices sl, sl+16, ...; the 16 lane sums are combined in lane order (deterministic).
-template <typename P>
-__global__ __launch_bounds__(256) void conv_wgrad_reduce_kernel(const P* __restrict__ slab, int S, int Cout, int Cin, int cin_pad,
-                                                                int k, P* __restrict__ dW, P* __restrict__ dbias) {
-  __shared__ P red[16][17];
-  const int KK = k * cin_pad;
-  const long per = (long)Cout * (KK + 1);
-  const int qi = threadIdx.x & 15, sl = threadIdx.x >> 4;
-  const long q = (long)blockIdx.x * 16 + qi;
-  P a = 0;
-  if (q < per) {
-#pragma unroll 8
-    for (int s = sl; s < S; s += 16) a += slab[(long)s * per + q];
-  }
-  red[sl][qi] = a;
-  __syncthreads();
-  if (sl == 0 && q < per) {
-    P t = 0;
-#pragma unroll
-    for (int i = 0; i < 16; ++i) t += red[i][qi];
-    const int o = (int)(q / (KK + 1)), col = (int)(q % (KK + 1));
-    const int j = col / cin_pad, ci = col % cin_pad;
-    if (col == KK) dbias[o] = t;
-    else if (ci < Cin) dW[((long)o * Cin + ci) * k + j] = t;
-  }
-}
-
 // ------------------------------------------------------------------------------ layout helpers
 // W[Cout][Cin][k] (P) -> wpack[Cout][k*cin_pad] (T, tap-major, zero padded channels)
 //                     -> wflip[cin_pad][k*Cout]  (T, wflip[ci][j*Cout + o] = W[o][ci][k-1-j])
@@ -640,10 +613,10 @@ static int convblock_bwd(const void* dout, int dout_ncl, const uint8_t* argmax, 
     EMB_CHECK_LAUNCH();
     rc = conv_first_bwd_wgrad(dout, dout_ncl, argmax, x, x_codes, wpack, bias, stats, coef, keep_scale, training, slab, &S, B, L, Cout, k, s);
     if (rc != EMB_OK) return rc == 1 ? EMB_ERR_ARG : rc;
-    const long n = (long)Cout * (KK + 1);
-    conv_wgrad_reduce_kernel<P><<<(int)((n + 15) / 16), 256, 0, s>>>(slab, S, Cout, Cin, cin_pad, k, (P*)dW, (P*)dbias);
-    EMB_CHECK_LAUNCH();
-    return EMB_OK;
+    ReduceJob j{};   // slabs -> dW (torch layout, real channels) / dbias, slices summed in fixed order (reduce.hip)
+    j.in = slab; j.out[0] = dW; j.out[1] = dbias; j.per = (long)Cout * (KK + 1); j.S = S; j.kind = RJ_CONV;
+    j.iv[0] = Cin; j.iv[1] = cin_pad; j.iv[2] = k;
+    return reduce_submit(j, sizeof(P) == 8, s);
   }
   {   // dgamma / dbeta are defined in eval mode too (x-hat then uses the running statistics)
     const int TT = w.rows_per_block, tiles_per_seq = cdiv(L, TT);
@@ -683,9 +656,11 @@ static int convblock_bwd(const void* dout, int dout_ncl, const uint8_t* argmax, 
     } else if (rc != EMB_OK) {
       return rc;
     }
-    const long n = (long)Cout * (KK + 1);
-    conv_wgrad_reduce_kernel<P><<<(int)((n + 15) / 16), 256, 0, s>>>(slab, S, Cout, Cin, cin_pad, k, (P*)dW, (P*)dbias);
-    EMB_CHECK_LAUNCH();
+    ReduceJob j{};   // slabs -> dW (torch layout, real channels) / dbias, slices summed in fixed order (reduce.hip)
+    j.in = slab; j.out[0] = dW; j.out[1] = dbias; j.per = (long)Cout * (KK + 1); j.S = S; j.kind = RJ_CONV;
+    j.iv[0] = Cin; j.iv[1] = cin_pad; j.iv[2] = k;
+    const int rcr = reduce_submit(j, sizeof(P) == 8, s);
+    if (rcr != EMB_OK) return rcr;
   }
   if (dx != nullptr) {   // dgrad: the same conv-view GEMM on dy with flipped taps
     int rc = launch_conv_direct(dtype_code<T>(), false, dy, wflip, nullptr, dx, nullptr, nullptr, B, L, Cout, k * Cout, cin_pad, pad, s);

@@ -11,6 +11,7 @@
 // argument struct indexed by a run-time modality made hipcc 7.2 re-associate the kernarg address into a
 // byte-granular scalar base, which s_load does not honour: the loaded pointers were garbage.)
 #include "gemm_tile.h"
+#include "reduce.h"
 
 namespace emb {
 
@@ -93,24 +94,6 @@ __global__ __launch_bounds__(kThreads) void embrace_bwd_kernel(const T* __restri
   }
 }
 
-// dW_m / db_m from the per-slice slabs of both modalities, slices summed in order (deterministic)
-template <typename P>
-__global__ void embrace_wgrad_reduce_kernel(const P* __restrict__ slab1, int S1, int N1, P* __restrict__ dW1, P* __restrict__ db1,
-                                            const P* __restrict__ slab0, int S0, int N0, P* __restrict__ dW0, P* __restrict__ db0,
-                                            int M) {
-  const long per1 = S1 > 1 ? (long)M * (N1 + 1) : 0, per0 = S0 > 1 ? (long)M * (N0 + 1) : 0;
-  long q = (long)blockIdx.x * blockDim.x + threadIdx.x;
-  const P* slab; P* dW; P* db; int S, N; long per;
-  if (q < per1) { slab = slab1; dW = dW1; db = db1; S = S1; N = N1; per = per1; }
-  else { q -= per1; if (q >= per0) return; slab = slab0; dW = dW0; db = db0; S = S0; N = N0; per = per0; }
-  P a = 0;
-#pragma unroll 8
-  for (int sl = 0; sl < S; ++sl) a += slab[(long)sl * per + q];
-  const int m = (int)(q / (N + 1)), n = (int)(q % (N + 1));
-  if (n == N) db[m] = a;
-  else dW[(long)m * N + n] = a;
-}
-
 template <typename T>
 static int bwd_dispatch(const void* dE, const uint8_t* code, const void* X0, const void* X1, const void* W0, const void* W1,
                         void* dX0, void* dX1, void* dW0, void* db0, void* dW1, void* db1, void* ws, int64_t ws_bytes, int B, int d0,
@@ -173,11 +156,18 @@ static int bwd_dispatch(const void* dE, const uint8_t* code, const void* X0, con
   }
   embrace_bwd_kernel<T><<<n, kThreads, lds, s>>>((const T*)dE, code, c, vec_e, dg1, wg1, dg0, wg0);
   EMB_CHECK_LAUNCH();
-  if (wg1.S > 1 || wg0.S > 1) {
-    const long total = (wg1.S > 1 ? (long)c * (d1 + 1) : 0) + (wg0.S > 1 ? (long)c * (d0 + 1) : 0);
-    embrace_wgrad_reduce_kernel<P><<<(int)((total + 255) / 256), 256, 0, s>>>(wg1.slab, wg1.S, d1, (P*)dW1, (P*)db1, wg0.slab, wg0.S, d0,
-                                                                             (P*)dW0, (P*)db0, c);
-    EMB_CHECK_LAUNCH();
+  // per-slice slabs -> dW_m / db_m, slices summed in fixed order (reduce.hip)
+  if (wg1.S > 1) {
+    ReduceJob j{};
+    j.in = wg1.slab; j.out[0] = dW1; j.out[1] = db1; j.per = (long)c * (d1 + 1); j.S = wg1.S; j.kind = RJ_LINEAR; j.iv[0] = d1;
+    const int rc = reduce_submit(j, sizeof(P) == 8, s);
+    if (rc != EMB_OK) return rc;
+  }
+  if (wg0.S > 1) {
+    ReduceJob j{};
+    j.in = wg0.slab; j.out[0] = dW0; j.out[1] = db0; j.per = (long)c * (d0 + 1); j.S = wg0.S; j.kind = RJ_LINEAR; j.iv[0] = d0;
+    const int rc = reduce_submit(j, sizeof(P) == 8, s);
+    if (rc != EMB_OK) return rc;
   }
   return EMB_OK;
 }

@@ -4,6 +4,7 @@
 // epilogue; backward applies the saved mask while dY is staged and folds the bias gradient into the
 // weight-gradient GEMM (virtual ones row), all in one launch.
 #include "gemm_tile.h"
+#include "reduce.h"
 
 namespace emb {
 
@@ -96,20 +97,6 @@ template <typename T> __global__ __launch_bounds__(kThreads) void linear_bwd_ker
   }
 }
 
-// dW[n][k], db[n] from the slab, slices summed in order (deterministic)
-template <typename P>
-__global__ void linear_wgrad_reduce_kernel(const P* __restrict__ slab, int S, int N, int K, P* __restrict__ dW, P* __restrict__ db) {
-  const long per = (long)N * (K + 1);
-  const long q = (long)blockIdx.x * blockDim.x + threadIdx.x;
-  if (q >= per) return;
-  P acc = 0;
-#pragma unroll 8
-  for (int s = 0; s < S; ++s) acc += slab[(long)s * per + q];
-  const int n = (int)(q / (K + 1)), k = (int)(q % (K + 1));
-  if (k == K) db[n] = acc;
-  else dW[(long)n * K + k] = acc;
-}
-
 template <typename T>
 static int linear_bwd_dispatch(const void* dY, const uint8_t* mask, const void* X, const void* W, void* dX, void* dW, void* db,
                                int relu, float dropout_p, void* ws, int64_t ws_bytes, int B, int K, int N, hipStream_t s) {
@@ -156,9 +143,10 @@ static int linear_bwd_dispatch(const void* dY, const uint8_t* mask, const void* 
   linear_bwd_kernel<T><<<a.nblocks, kThreads, lds, s>>>(a);
   EMB_CHECK_LAUNCH();
   if (a.S > 1) {
-    const long per = (long)N * (K + 1);
-    linear_wgrad_reduce_kernel<P><<<(int)((per + 255) / 256), 256, 0, s>>>(a.slab, a.S, N, K, (P*)dW, (P*)db);
-    EMB_CHECK_LAUNCH();
+    ReduceJob j{};   // dW[n][k], db[n] from the slab, slices summed in fixed order (reduce.hip)
+    j.in = a.slab; j.out[0] = dW; j.out[1] = db; j.per = (long)N * (K + 1); j.S = a.S; j.kind = RJ_LINEAR; j.iv[0] = K;
+    const int rc = reduce_submit(j, sizeof(P) == 8, s);
+    if (rc != EMB_OK) return rc;
   }
   return EMB_OK;
 }

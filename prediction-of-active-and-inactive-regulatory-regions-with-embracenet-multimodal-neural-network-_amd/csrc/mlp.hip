@@ -12,6 +12,7 @@
 // (deterministic).  Eligibility is checked by emb_mlp_supported(); larger layers use the GEMM kernels of linear.hip.
 #include "common.h"
 #include "philox.h"
+#include "reduce.h"
 
 namespace emb {
 
@@ -330,25 +331,6 @@ __global__ __launch_bounds__(kMlpThreads) void mlp_bwd_kernel(const MlpBwdArgs<T
   MLP_T(14);
 }
 
-template <typename P> __global__ void mlp_reduce_kernel(const P* __restrict__ part, const MlpReduceArgs a) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= a.total) return;
-  P s = 0;
-#pragma unroll 8
-  for (int b = 0; b < a.nblk; ++b) s += part[(long)b * a.total + i];
-  int off = i;
-#define EMB_MLP_OUT(l)                                                         \
-  if (a.L > l) {                                                               \
-    const int nw = a.N[l] * a.K[l];                                            \
-    if (off < nw) { ((P*)a.dW[l])[off] = s; return; }                          \
-    off -= nw;                                                                 \
-    if (off < a.N[l]) { ((P*)a.db[l])[off] = s; return; }                      \
-    off -= a.N[l];                                                             \
-  }
-  EMB_MLP_OUT(0) EMB_MLP_OUT(1) EMB_MLP_OUT(2) EMB_MLP_OUT(3)
-#undef EMB_MLP_OUT
-}
-
 static int mlp_pitch(int F, const int* N, int L) {
   int m = F;
   for (int l = 0; l < L; ++l) m = N[l] > m ? N[l] : m;
@@ -438,9 +420,10 @@ static int mlp_bwd_t(const void* x, const void* const* W, const void* const* h, 
   }
   mlp_bwd_kernel<T><<<nblk, kMlpThreads, lds, s>>>(a, pitch);
   EMB_CHECK_LAUNCH();
-  mlp_reduce_kernel<P><<<cdiv(total, 256), 256, 0, s>>>((const P*)ws, ra);
-  EMB_CHECK_LAUNCH();
-  return EMB_OK;
+  ReduceJob j{};   // per-workgroup partials -> dW_l / db_l, workgroups summed in fixed order (reduce.hip)
+  j.in = ws; j.per = total; j.S = nblk; j.kind = RJ_MLP; j.iv[0] = L;
+  for (int l = 0; l < L; ++l) { j.out[l] = ra.dW[l]; j.out[4 + l] = ra.db[l]; j.iv[1 + l] = ra.N[l]; j.iv[5 + l] = ra.K[l]; }
+  return reduce_submit(j, sizeof(P) == 8, s);
 }
 
 }  // namespace emb

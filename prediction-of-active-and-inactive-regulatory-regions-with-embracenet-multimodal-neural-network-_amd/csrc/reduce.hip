@@ -1,0 +1,133 @@
+// One kernel for all slab reductions (see reduce.h).
+#include <vector>
+
+#include "reduce.h"
+
+namespace emb {
+
+constexpr int kMaxJobs = 8;
+struct DevJob {
+  ReduceJob j;
+  int lanes, blk_end;   // slice lanes per element (power of two <= 16); exclusive prefix end of this job's blocks
+};
+struct ReduceTable {
+  DevJob d[kMaxJobs];
+  int n;
+};
+
+template <typename P> __device__ __forceinline__ void reduce_write(const ReduceJob& j, long q, P t) {
+  if (j.kind == RJ_LINEAR) {
+    const int N = j.iv[0];
+    const long m = q / (N + 1);
+    const int n = (int)(q - m * (N + 1));
+    if (n == N) ((P*)j.out[1])[m] = t;
+    else ((P*)j.out[0])[m * N + n] = t;
+  } else if (j.kind == RJ_CONV) {   // slab row = [k*cin_pad tap-major columns | bias]; dW in torch layout [Cout][Cin][k]
+    const int Cin = j.iv[0], cin_pad = j.iv[1], k = j.iv[2], KK = k * cin_pad;
+    const int o = (int)(q / (KK + 1)), col = (int)(q - (long)o * (KK + 1));
+    const int tap = col / cin_pad, ci = col - tap * cin_pad;
+    if (col == KK) ((P*)j.out[1])[o] = t;
+    else if (ci < Cin) ((P*)j.out[0])[((long)o * Cin + ci) * k + tap] = t;
+  } else {                          // RJ_MLP: per layer [N*K weights | N biases]
+    long off = q;
+    const int L = j.iv[0];
+#pragma unroll
+    for (int l = 0; l < 4; ++l) {
+      if (l < L) {
+        const long nw = (long)j.iv[1 + l] * j.iv[5 + l];
+        if (off < nw) { ((P*)j.out[l])[off] = t; return; }
+        off -= nw;
+        if (off < j.iv[1 + l]) { ((P*)j.out[4 + l])[off] = t; return; }
+        off -= j.iv[1 + l];
+      }
+    }
+  }
+}
+
+// block = (256 / lanes) elements x `lanes` slice lanes: lane sl sums slices sl, sl + lanes, ...; the lane sums meet in lane order
+template <typename P> __global__ __launch_bounds__(256) void multi_reduce_kernel(const ReduceTable tab) {
+  __shared__ ReduceTable t;
+  __shared__ P red[256];
+  {
+    const unsigned* src = reinterpret_cast<const unsigned*>(&tab);
+    unsigned* dst = reinterpret_cast<unsigned*>(&t);
+    for (int i = threadIdx.x; i < (int)(sizeof(ReduceTable) / 4); i += 256) dst[i] = src[i];
+  }
+  __syncthreads();
+  int ji = 0;
+  while (ji < t.n - 1 && (int)blockIdx.x >= t.d[ji].blk_end) ++ji;
+  const DevJob& d = t.d[ji];
+  const int bid = (int)blockIdx.x - (ji == 0 ? 0 : t.d[ji - 1].blk_end);
+  const int lanes = d.lanes, qpb = 256 / lanes, qi = threadIdx.x % qpb, sl = threadIdx.x / qpb;
+  const long per = d.j.per, q = (long)bid * qpb + qi;
+  const P* in = (const P*)d.j.in;
+  P a = 0;
+  if (q < per) {
+#pragma unroll 8
+    for (int s = sl; s < d.j.S; s += lanes) a += in[(long)s * per + q];
+  }
+  red[sl * qpb + qi] = a;
+  __syncthreads();
+  if (sl == 0 && q < per) {
+    P sum = 0;
+    for (int i = 0; i < lanes; ++i) sum += red[i * qpb + qi];
+    reduce_write<P>(d.j, q, sum);
+  }
+}
+
+struct Pending {
+  std::vector<ReduceJob> f32, f64;
+};
+static Pending& pending() {
+  static Pending p;
+  return p;
+}
+static bool g_defer = false;
+
+template <typename P> static int launch_jobs(const ReduceJob* jobs, int n, hipStream_t s) {
+  for (int off = 0; off < n; off += kMaxJobs) {
+    ReduceTable t{};
+    const int cnt = n - off < kMaxJobs ? n - off : kMaxJobs;
+    int blocks = 0;
+    for (int i = 0; i < cnt; ++i) {
+      t.d[i].j = jobs[off + i];
+      int lanes = 1;
+      while (lanes < 16 && lanes < t.d[i].j.S) lanes *= 2;
+      t.d[i].lanes = lanes;
+      blocks += (int)((t.d[i].j.per + (256 / lanes) - 1) / (256 / lanes));
+      t.d[i].blk_end = blocks;
+    }
+    t.n = cnt;
+    if (blocks == 0) continue;
+    multi_reduce_kernel<P><<<blocks, 256, 0, s>>>(t);
+    EMB_CHECK_LAUNCH();
+  }
+  return EMB_OK;
+}
+
+int reduce_submit(const ReduceJob& job, bool is_double, hipStream_t s) {
+  if (job.per <= 0 || job.S <= 0) return EMB_OK;
+  if (g_defer) {
+    std::vector<ReduceJob>& v = is_double ? pending().f64 : pending().f32;
+    v.push_back(job);
+    return EMB_OK;
+  }
+  return is_double ? launch_jobs<double>(&job, 1, s) : launch_jobs<float>(&job, 1, s);
+}
+
+}  // namespace emb
+
+extern "C" int emb_reduce_defer(int on) {
+  emb::g_defer = on != 0;
+  return EMB_OK;
+}
+
+extern "C" int emb_reduce_flush(emb_stream_t stream) {
+  emb::Pending& p = emb::pending();
+  int rc = EMB_OK;
+  if (!p.f32.empty()) rc = emb::launch_jobs<float>(p.f32.data(), (int)p.f32.size(), (hipStream_t)stream);
+  if (rc == EMB_OK && !p.f64.empty()) rc = emb::launch_jobs<double>(p.f64.data(), (int)p.f64.size(), (hipStream_t)stream);
+  p.f32.clear();
+  p.f64.clear();
+  return rc;
+}

@@ -217,7 +217,7 @@ class _EmbraceFn(torch.autograd.Function):
         sk = ctx.sinks
         dW0, db0 = _out(sk[0], (c, d0), P, dev), _out(sk[1], (c,), P, dev)
         dW1, db1 = _out(sk[2], (c, d1), P, dev), _out(sk[3], (c,), P, dev)
-        ws = _workspace(dev, 1 << 24)
+        ws = _workspace(dev, 1 << 24, "embrace")
         check(_lib.lib().emb_embrace_bwd(ptr(dE), ptr(code), ptr(x0c), ptr(x1c), ptr(w0c), ptr(w1c), ptr(dX0), ptr(dX1),
                                          ptr(dW0), ptr(db0), ptr(dW1), ptr(db1), ptr(ws), ws.numel(), B, d0, d1, c,
                                          DTYPE_CODE[T], stream()), "emb_embrace_bwd")
@@ -252,6 +252,7 @@ class _LinearFn(torch.autograd.Function):
                                         DTYPE_CODE[T], stream()), "emb_linear_fwd")
         ctx.save_for_backward(xc, wc, mask)
         ctx.cfg = (T, bool(relu), float(dropout_p), x.dtype, w.dtype, b.dtype)
+        ctx.layer_id = int(layer_id)
         ctx.sinks = (grad_sink(w, P), grad_sink(b, P))
         return y
 
@@ -266,7 +267,7 @@ class _LinearFn(torch.autograd.Function):
         dx = torch.empty(B, K, dtype=T, device=xc.device) if ctx.needs_input_grad[0] else None
         sk = ctx.sinks
         dw, db = _out(sk[0], (N, K), P, xc.device), _out(sk[1], (N,), P, xc.device)
-        ws = _workspace(xc.device, 1 << 22)
+        ws = _workspace(xc.device, 1 << 22, f"linear{ctx.layer_id}")
         check(_lib.lib().emb_linear_bwd(ptr(dy), ptr(mask), ptr(xc), ptr(wc), ptr(dx), ptr(dw), ptr(db), int(relu),
                                         dropout_p, ptr(ws), ws.numel(), B, K, N, DTYPE_CODE[T], stream()), "emb_linear_bwd")
         cast = lambda g, d: None if g is None else (g if g.dtype == d else g.to(d))
@@ -313,6 +314,7 @@ class _MlpFn(torch.autograd.Function):
         check(_lib.lib().emb_mlp_fwd(ptr(xc), _parr(Ws), _parr(bs), _parr(hs), _parr(masks), iN, irelu, fdrop, ilid, L_, B, Fin,
                                      rng.seed, rng.step_val, ptr(rng.step_dev), rng.row0, DTYPE_CODE[T], stream()), "emb_mlp_fwd")
         ctx.save_for_backward(xc, *Ws, *hs, *[m if m is not None else hs[0] for m in masks])
+        ctx.ws_tag = f"mlp{int(meta[0][2])}"
         ctx.cfg = (T, L_, Ns, [bool(m[0]) for m in meta], [float(m[1]) for m in meta], [m is not None for m in masks],
                    x.dtype, [params[i].dtype for i in range(2 * L_)])
         ctx.sinks = tuple(grad_sink(q, P) for q in params)
@@ -335,7 +337,7 @@ class _MlpFn(torch.autograd.Function):
         dbs = [_out(sk[2 * l + 1], (Ns[l],), P, dev) for l in range(L_)]
         iN = (_ct.c_int * L_)(*Ns)
         need = _lib.lib().emb_mlp_workspace_bytes(Fin, iN, L_, B, DTYPE_CODE[T])
-        ws = _workspace(dev, max(need, 1 << 22))
+        ws = _workspace(dev, max(need, 1 << 22), ctx.ws_tag)
         irelu = (_ct.c_int * L_)(*[int(r) for r in relus])
         fdrop = (_ct.c_float * L_)(*drops)
         check(_lib.lib().emb_mlp_bwd(ptr(xc), _parr(Ws), _parr(hs), _parr(masks), ptr(dy), ptr(dx), _parr(dWs), _parr(dbs), iN, irelu,
@@ -445,10 +447,22 @@ def cast(src, dtype, out=None):
 _WORKSPACE = {}
 
 
-def _workspace(device, nbytes):
-    """Scratch buffer of the CURRENT stream (kernels of different streams may run concurrently: the epigenomic
-    pre-network overlaps the sequence pre-network, see EmbraceNetMultimodal.forward)."""
-    key = (device, torch.cuda.current_stream(device).cuda_stream)
+def reduce_defer(enable):
+    """Queue the weight-gradient slab reductions of the backward kernels instead of launching one per layer; `reduce_flush()`
+    then runs them all in ONE launch.  Between the two the parameter gradients are incomplete (training.StepRunner and
+    bench.py bracket `backward()` with them).  See include/embrace_hip.h."""
+    check(_lib.lib().emb_reduce_defer(int(bool(enable))), "emb_reduce_defer")
+
+
+def reduce_flush():
+    check(_lib.lib().emb_reduce_flush(stream()), "emb_reduce_flush")
+
+
+def _workspace(device, nbytes, tag=""):
+    """Scratch buffer of the CURRENT stream and call site `tag`: kernels of different streams may run concurrently (the
+    epigenomic pre-network overlaps the sequence pre-network), and a deferred slab reduction still reads one call site's
+    buffer after the next backward kernels have run -- every user keeps its own."""
+    key = (device, torch.cuda.current_stream(device).cuda_stream, tag)
     buf = _WORKSPACE.get(key)
     if buf is None or buf.numel() < nbytes:
         buf = torch.empty(int(nbytes), dtype=torch.uint8, device=device)
@@ -512,7 +526,7 @@ class _ConvStackFn(torch.autograd.Function):
             out = torch.empty((B, Cout, Lp) if last else (B, Lp, Cout), dtype=T, device=dev)
             argmax = torch.empty(B, Lp, Cout, dtype=torch.uint8, device=dev)
             nbytes = L_.emb_convblock_workspace_bytes(B, L, cin_pad, Cout, k, code)
-            ws = _workspace(dev, nbytes)
+            ws = _workspace(dev, nbytes, f"conv{i}")
             check(L_.emb_convblock_fwd(ptr(cur), ptr(wpack), ptr(b.detach()), ptr(g.detach()), ptr(beta.detach()), ptr(rmean),
                                        ptr(rvar), int(training), float(m["momentum"]), float(m["eps"]), float(m["drop_p"]),
                                        rng.seed, rng.step_val, ptr(rng.step_dev), rng.row0, int(m["layer_id"]), ptr(y),
@@ -546,7 +560,7 @@ class _ConvStackFn(torch.autograd.Function):
             dW = _out(sk[0], (Cout, Cin, k), P, dev)
             db, dgam, dbeta = (_out(sk[j], (Cout,), P, dev) for j in (1, 2, 3))
             nbytes = L_.emb_convblock_workspace_bytes(B, L, cin_pad, Cout, k, code)
-            ws = _workspace(dev, nbytes)
+            ws = _workspace(dev, nbytes, f"conv{i}")
             check(L_.emb_convblock_bwd(ptr(g), int(last), ptr(argmax), None if fused else ptr(y), ptr(stats), ptr(xin),
                                        ptr(wflip) if i > 0 else None, ptr(wpack), ptr(bias), drop_p, training, ptr(dx), ptr(dW),
                                        ptr(db), ptr(dgam),

@@ -138,7 +138,15 @@ class StepRunner:
     def train_step(self, x_1, x_2, target, table):
         self.optimizer.zero_grad()
         output, loss, dlogits = self._forward_loss(x_1, x_2, target, True, table)
-        output.backward(dlogits)        # the loss is the root of the graph: d loss / d logits comes from the loss kernel
+        deferred = output.is_cuda
+        if deferred:
+            F_.reduce_defer(True)       # the per-layer slab reductions of the backward are queued ...
+        try:
+            output.backward(dlogits)    # the loss is the root of the graph: d loss / d logits comes from the loss kernel
+        finally:
+            if deferred:
+                F_.reduce_defer(False)
+                F_.reduce_flush()       # ... and run in one launch here
         self.bucket.allreduce()
         if self.opt_tick is not None:
             self.optimizer.external_tick = True             # already advanced by the loss kernel of this step
