@@ -9,6 +9,7 @@ constexpr int kMaxJobs = 8;
 struct DevJob {
   ReduceJob j;
   int lanes, blk_end;   // slice lanes per element (power of two <= 16); exclusive prefix end of this job's blocks
+  int vec;              // elements per thread: 4 (16-byte loads; per % 4 == 0, aligned) or 1
 };
 struct ReduceTable {
   DevJob d[kMaxJobs];
@@ -47,7 +48,7 @@ template <typename P> __device__ __forceinline__ void reduce_write(const ReduceJ
 // block = (256 / lanes) elements x `lanes` slice lanes: lane sl sums slices sl, sl + lanes, ...; the lane sums meet in lane order
 template <typename P> __global__ __launch_bounds__(256) void multi_reduce_kernel(const ReduceTable tab) {
   __shared__ ReduceTable t;
-  __shared__ P red[256];
+  __shared__ P red[4][256];
   {
     const unsigned* src = reinterpret_cast<const unsigned*>(&tab);
     unsigned* dst = reinterpret_cast<unsigned*>(&t);
@@ -59,18 +60,40 @@ template <typename P> __global__ __launch_bounds__(256) void multi_reduce_kernel
   const DevJob& d = t.d[ji];
   const int bid = (int)blockIdx.x - (ji == 0 ? 0 : t.d[ji - 1].blk_end);
   const int lanes = d.lanes, qpb = 256 / lanes, qi = threadIdx.x % qpb, sl = threadIdx.x / qpb;
-  const long per = d.j.per, q = (long)bid * qpb + qi;
+  const long per = d.j.per;
   const P* in = (const P*)d.j.in;
+  if (d.vec == 4) {   // four consecutive elements per thread, 16-byte (P = float) loads
+    typedef P P4 __attribute__((ext_vector_type(4)));
+    const long q = ((long)bid * qpb + qi) * 4;
+    P4 a = {0, 0, 0, 0};
+    if (q < per) {
+#pragma unroll 8
+      for (int s = sl; s < d.j.S; s += lanes) a += *reinterpret_cast<const P4*>(in + (long)s * per + q);
+    }
+#pragma unroll
+    for (int e = 0; e < 4; ++e) red[e][sl * qpb + qi] = a[e];
+    __syncthreads();
+    if (sl == 0 && q < per) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        P sum = 0;
+        for (int i = 0; i < lanes; ++i) sum += red[e][i * qpb + qi];
+        reduce_write<P>(d.j, q + e, sum);
+      }
+    }
+    return;
+  }
+  const long q = (long)bid * qpb + qi;
   P a = 0;
   if (q < per) {
 #pragma unroll 8
     for (int s = sl; s < d.j.S; s += lanes) a += in[(long)s * per + q];
   }
-  red[sl * qpb + qi] = a;
+  red[0][sl * qpb + qi] = a;
   __syncthreads();
   if (sl == 0 && q < per) {
     P sum = 0;
-    for (int i = 0; i < lanes; ++i) sum += red[i * qpb + qi];
+    for (int i = 0; i < lanes; ++i) sum += red[0][i * qpb + qi];
     reduce_write<P>(d.j, q, sum);
   }
 }
@@ -94,7 +117,9 @@ template <typename P> static int launch_jobs(const ReduceJob* jobs, int n, hipSt
       int lanes = 1;
       while (lanes < 16 && lanes < t.d[i].j.S) lanes *= 2;
       t.d[i].lanes = lanes;
-      blocks += (int)((t.d[i].j.per + (256 / lanes) - 1) / (256 / lanes));
+      t.d[i].vec = (t.d[i].j.per % 4 == 0 && aligned16(t.d[i].j.in)) ? 4 : 1;
+      const long epb = (long)(256 / lanes) * t.d[i].vec;   // elements per block
+      blocks += (int)((t.d[i].j.per + epb - 1) / epb);
       t.d[i].blk_end = blocks;
     }
     t.n = cnt;
