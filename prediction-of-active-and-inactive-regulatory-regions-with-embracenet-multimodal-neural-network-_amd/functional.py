@@ -459,10 +459,10 @@ def reduce_flush():
 
 
 def _workspace(device, nbytes, tag=""):
-    """Scratch buffer of the CURRENT stream and call site `tag`: kernels of different streams may run concurrently (the
-    epigenomic pre-network overlaps the sequence pre-network), and a deferred slab reduction still reads one call site's
-    buffer after the next backward kernels have run -- every user keeps its own."""
-    key = (device, torch.cuda.current_stream(device).cuda_stream, tag)
+    """Scratch buffer of call site `tag`: kernels of different streams may run concurrently (the epigenomic pre-network
+    overlaps the sequence pre-network), and a deferred slab reduction still reads one call site's buffer after the next
+    backward kernels have run -- every user keeps its own (and keeps it across steps: nothing is allocated under capture)."""
+    key = (torch.device(device), tag)
     buf = _WORKSPACE.get(key)
     if buf is None or buf.numel() < nbytes:
         buf = torch.empty(int(nbytes), dtype=torch.uint8, device=device)
