@@ -8,7 +8,9 @@
 //   forward   F_STATS   conv -> per-channel sums of z and z^2                       (no activation traffic)
 //             (bn_finalize_kernel)
 //             F_APPLY   conv -> BN -> ReLU -> LDS tile -> MaxPool/argmax/Dropout -> pooled output (16 MB) + argmax bytes
-//   backward  F_BSUMS   conv; gather of the pooled gradient through the argmax bytes -> sums of dy and dy*xhat
+//   backward  F_BSUMS   conv -> xhat tile in LDS; the two batch sums are taken in WINDOW space -- sum dy = sum of the pooled
+//                       gradients that have a target, sum dy*xhat = sum of g[p][c] * xhat[2p + argmax(p,c)][c] -- one LDS
+//                       read per pooled element, no dense dy
 //             (bn_bwd_finalize_kernel)
 //             F_BWGRAD  conv; gather; dz = A*dy + Bc*z + D -> LDS tile -> weight-gradient MFMAs -> per-workgroup slabs
 //             (conv_wgrad_reduce_kernel)
@@ -75,7 +77,9 @@ __global__ __launch_bounds__(256 * CH) void first_kernel(const FirstArgs a) {
   constexpr int DPP = BN + 8, AMP = BN + 8;             // pitches of the pooled-gradient rows (bf16) / argmax rows (bytes)
   T* xs = reinterpret_cast<T*>(arena);                                 // [xrows][8]
   T* zt = xs + ((xrows * XS + 7) & ~7);                                // F_APPLY: BN/ReLU output, F_BWGRAD: dz; [256][ZP] bf16
-  T* dp = zt + ((MODE == F_APPLY || MODE == F_BWGRAD) ? kFBT * ZP : 0);   // backward: pooled gradient [SB*Lp][DPP]
+  constexpr int XP = BN + 4;                                           // F_BSUMS: fp32 xhat tile [256][XP] in the zt region
+  float* xt = reinterpret_cast<float*>(zt);
+  T* dp = zt + ((MODE == F_APPLY || MODE == F_BWGRAD) ? kFBT * ZP : (MODE == F_BSUMS ? 2 * kFBT * XP : 0));   // backward: pooled gradient [SB*Lp][DPP]
   uint8_t* am = reinterpret_cast<uint8_t*>(dp + (MODE >= F_BSUMS ? SB * Lp * DPP : 0));   // backward: argmax bytes [SB*Lp][AMP]
   int* rowmap = reinterpret_cast<int*>(am + (MODE >= F_BSUMS ? ((SB * Lp * AMP + 15) & ~15) : 0));   // F_BWGRAD: [256]
   float* red = reinterpret_cast<float*>(rowmap + (MODE == F_BWGRAD ? kFBT : 0));                      // [4][2][BN]
@@ -222,8 +226,7 @@ __global__ __launch_bounds__(256 * CH) void first_kernel(const FirstArgs a) {
     const uint8_t* asrc = a.argmax + (long)b0 * Lp * C;
 #pragma unroll
     for (int i = 0; i < NIT; ++i) {
-#pragma unroll
-      for (int e = 0; e < 8; ++e) gv[i][e] = (T)0.0f;
+      gv[i] = __builtin_bit_cast(bf16x8, make_uint4(0u, 0u, 0u, 0u));   // (whole-vector write: element writes would push the array to scratch)
       av[i] = 0x8080808080808080ull;                   // "dropped": matches no window offset
       if (it_pc[i] >= 0 && (it_pc[i] >> 8) < nseq) {
         const long off = (long)(threadIdx.x + i * NTHR) * 8;     // items are laid out exactly as [sq][p][c]
@@ -235,6 +238,10 @@ __global__ __launch_bounds__(256 * CH) void first_kernel(const FirstArgs a) {
   if (MODE >= F_BSUMS) {
     if (!a.ncl && tm_begin < tm_end) issue_g(tm_begin);
   }
+
+  float q1[8], q2[8];   // F_BSUMS: this thread's sums of g and g*xhat for its 8 channels (items of a thread share c0)
+#pragma unroll
+  for (int e = 0; e < 8; ++e) { q1[e] = 0.0f; q2[e] = 0.0f; }
 
   FIRST_T(1);
   for (int tm = tm_begin; tm < tm_end; ++tm) {
@@ -257,7 +264,7 @@ __global__ __launch_bounds__(256 * CH) void first_kernel(const FirstArgs a) {
       if (!a.ncl) {
 #pragma unroll
         for (int i = 0; i < NIT; ++i)
-          if (it_pc[i] >= 0) {
+          if (MODE == F_BWGRAD && it_pc[i] >= 0) {   // F_BSUMS consumes the registers directly (window-space sums)
             const int sp = it_row[i] & 0xFFFF, c0 = it_row[i] >> 16;
             *reinterpret_cast<bf16x8*>(dp + sp * DPP + c0) = gv[i];
             *reinterpret_cast<uint64_t*>(am + sp * AMP + c0) = av[i];
@@ -275,7 +282,7 @@ __global__ __launch_bounds__(256 * CH) void first_kernel(const FirstArgs a) {
     FIRST_T(2 + (tm - tm_begin) * 8 + 2);
     if (tm + 1 < tm_end) {
       issue_x(tm + 1);
-      if (MODE >= F_BSUMS) {
+      if (MODE == F_BWGRAD) {
         if (!a.ncl) issue_g(tm + 1);
       }
     }
@@ -344,6 +351,17 @@ __global__ __launch_bounds__(256 * CH) void first_kernel(const FirstArgs a) {
             bf16x4 o = {ov[0], ov[1], ov[2], ov[3]};
             *reinterpret_cast<bf16x4*>(dst) = o;
           }
+        } else if (MODE == F_BSUMS) {
+          float* dst = xt + row * XP + gcol + g * CPL;   // xhat of this lane's row (0 outside the batch)
+#pragma unroll
+          for (int mt = 0; mt < MT; ++mt) {
+            float4 o;
+            o.x = rv ? (acc[mt][j][0] - k0[mt][0]) * k1[mt][0] : 0.0f;
+            o.y = rv ? (acc[mt][j][1] - k0[mt][1]) * k1[mt][1] : 0.0f;
+            o.z = rv ? (acc[mt][j][2] - k0[mt][2]) * k1[mt][2] : 0.0f;
+            o.w = rv ? (acc[mt][j][3] - k0[mt][3]) * k1[mt][3] : 0.0f;
+            *reinterpret_cast<float4*>(dst + mt * 4) = o;
+          }
         } else {
           // dy[ch] of this lane's row t: the windows containing t are p = t/2 - k, k = 0..4, and window p selected row t iff
           // its argmax byte equals t - 2p = (t & 1) + 2k (ReLU zeros / dropped elements carry bit 6 / 7: never equal)
@@ -372,16 +390,7 @@ __global__ __launch_bounds__(256 * CH) void first_kernel(const FirstArgs a) {
 #pragma unroll
             for (int e = 0; e < CPL; ++e) dy[e] *= a.keep_scale;
           }
-          if (MODE == F_BSUMS) {
-#pragma unroll
-            for (int mt = 0; mt < MT; ++mt)
-#pragma unroll
-              for (int r = 0; r < 4; ++r) {
-                const float d = dy[mt * 4 + r];
-                s1[mt][r] += d;
-                s2[mt][r] += d * ((acc[mt][j][r] - k0[mt][r]) * k1[mt][r]);
-              }
-          } else {   // F_BWGRAD
+          {   // F_BWGRAD
             T ov[CPL];
 #pragma unroll
             for (int mt = 0; mt < MT; ++mt)
@@ -409,6 +418,37 @@ __global__ __launch_bounds__(256 * CH) void first_kernel(const FirstArgs a) {
     }
 
     FIRST_T(2 + (tm - tm_begin) * 8 + 3);
+    if (MODE == F_BSUMS) {
+      __syncthreads();                                 // xhat tile complete
+#pragma unroll
+      for (int i = 0; i < NIT; ++i) {
+        if (it_pc[i] >= 0 && (it_pc[i] >> 8) < nseq) {
+          const int sp = it_row[i] & 0xFFFF, c0 = it_row[i] >> 16, sq = it_pc[i] >> 8, p = it_pc[i] & 0xFF;
+          bf16x8 gq;
+          uint64_t aq;
+          if (!a.ncl) {
+            gq = gv[i];
+            aq = av[i];
+          } else {
+            gq = *reinterpret_cast<const bf16x8*>(dp + sp * DPP + c0);
+            aq = *reinterpret_cast<const uint64_t*>(am + sp * AMP + c0);
+          }
+          const float* xrow0 = xt + (sq * L + 2 * p) * XP + c0;
+#pragma unroll
+          for (int e = 0; e < 8; ++e) {
+            const int code = (int)((aq >> (8 * e)) & 0xFF);
+            const bool ok = code < 0x40;                 // bit 6 / 7: ReLU zero / dropped -> no gradient
+            const float gval = ok ? (float)gq[e] * a.keep_scale : 0.0f;
+            const float xh = xrow0[(ok ? code : 0) * XP + e];
+            q1[e] += gval;
+            q2[e] += gval * xh;
+          }
+        }
+      }
+      if (tm + 1 < tm_end) {
+        if (!a.ncl) issue_g(tm + 1);                   // the registers are free again
+      }
+    }
     if (MODE == F_APPLY) {
       __syncthreads();
       // MaxPool(10, 2) + argmax + Dropout over the tile's sequences; thread = (sequence, window, 8 channels)
@@ -512,7 +552,23 @@ __global__ __launch_bounds__(256 * CH) void first_kernel(const FirstArgs a) {
   }
 
   FIRST_T(40);
-  if (MODE == F_STATS || MODE == F_BSUMS) {   // one partial row per workgroup
+  if (MODE == F_BSUMS) {   // one partial row per workgroup: threads tid = c8 + CV*m share the channels 8*c8 .. 8*c8+7
+    __syncthreads();
+    float* red2 = xt;                                  // [NTHR][16]
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      red2[threadIdx.x * 16 + e] = q1[e];
+      red2[threadIdx.x * 16 + 8 + e] = q2[e];
+    }
+    __syncthreads();
+    if (threadIdx.x < 2 * BN) {
+      const int c = threadIdx.x % BN, which = threadIdx.x / BN, c8 = c >> 3, e = c & 7;
+      float t = 0.0f;
+      for (int m = 0; m < NTHR / CV; ++m) t += red2[(c8 + CV * m) * 16 + which * 8 + e];
+      if (c < C) a.partial[((long)bm * 2 + which) * C + c] = t;
+    }
+  }
+  if (MODE == F_STATS) {   // one partial row per workgroup
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
@@ -581,6 +637,7 @@ static size_t first_lds(int mode, const FirstGeom& gm, int Lp, int C) {
   const int BN = C, ZP = BN + 8, DPP = BN + 8, AMP = BN + 8;
   size_t bytes = (((size_t)gm.xrows * 8 + 7) & ~(size_t)7) * 2;
   if (mode == F_APPLY || mode == F_BWGRAD) bytes += (size_t)kFBT * ZP * 2;
+  if (mode == F_BSUMS) bytes += (size_t)kFBT * (BN + 4) * 4;
   if (mode >= F_BSUMS) bytes += (size_t)gm.SB * Lp * DPP * 2 + (((size_t)gm.SB * Lp * AMP + 15) & ~(size_t)15);
   if (mode == F_BWGRAD) bytes += kFBT * sizeof(int);
   bytes += (size_t)4 * 2 * BN * sizeof(float);
