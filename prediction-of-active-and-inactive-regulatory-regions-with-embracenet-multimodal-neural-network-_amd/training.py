@@ -85,11 +85,25 @@ def fused_ticks(model, optimizer, device):
     return tuple(ticks)
 
 
+GRAPH_STEPS = False          # default of StepRunner(graph=None): replay whole steps as hipGraphs (set_graph_steps)
+_GRAPH_WARMUP = 2            # eager steps of a batch shape before it is captured (allocations, optimizer state, packs)
+
+
+def set_graph_steps(enable):
+    """Let fit_multimodal / Kfold_CV_Multimodal replay whole train / eval steps as hipGraphs (one per batch shape) instead
+    of launching their ~26 kernels from Python every batch.  Needs the device RNG (``rng_mode == "philox"``), a fused
+    optimizer of this package and a single process; anything else keeps running eagerly.  Results are identical."""
+    global GRAPH_STEPS
+    GRAPH_STEPS = bool(enable)
+
+
 class StepRunner:
     """One train or eval step of training_models_multimodal.py:132-163 / :167-192 on device tensors."""
 
-    def __init__(self, model, optimizer, device):
+    def __init__(self, model, optimizer, device, graph=None):
         self.model, self.optimizer, self.device = model, optimizer, device
+        self.graph = GRAPH_STEPS if graph is None else bool(graph)
+        self._graphs = {}
         self.bucket = D.GradBucket(model.parameters()) if optimizer is not None else None
         self.counts = torch.zeros(2, dtype=torch.int64, device=device)
         on_gpu = torch.device(device).type == "cuda"
@@ -104,6 +118,53 @@ class StepRunner:
         row0, rows = D.shard_rows(B, D.rank(), world)
         sl = slice(row0, row0 + rows)
         return x_1[sl], x_2[sl], target[sl], row0
+
+    # ---- hipGraph replay of whole steps ---------------------------------------------------------------------------------
+    def _graphable(self, training):
+        m = self.model
+        if not (self.graph and torch.device(self.device).type == "cuda" and D.world_size() == 1):
+            return False
+        if getattr(m, "rng_mode", None) != "philox" or self.model_tick is None:
+            return False
+        return (not training) or self.opt_tick is not None
+
+    def _graph_step(self, training, x_1, x_2, target, table):
+        """Returns (output, loss) from a captured step, or None when this batch shape is still warming up / not eligible."""
+        if not self._graphable(training):
+            return None
+        model, dev = self.model, self.device
+        dt = getattr(model, "compute_dtype", None) or _input_dtype(model)
+        dt2 = torch.uint8 if x_2.dtype == torch.uint8 else dt
+        key = (bool(training), bool(model.training), tuple(x_1.shape), tuple(x_2.shape), dt, dt2, next(model.parameters()).data_ptr())
+        ent = self._graphs.get(key)
+        if ent is None:
+            ent = self._graphs[key] = {"seen": 0}
+        if "g" not in ent:
+            ent["seen"] += 1
+            if ent["seen"] <= _GRAPH_WARMUP:
+                return None                                 # eager (the caller's normal path)
+            st = ent["static"] = dict(
+                x1=torch.empty(tuple(x_1.shape), dtype=dt, device=dev), x2=torch.empty(tuple(x_2.shape), dtype=dt2, device=dev),
+                y=torch.empty(target.reshape(-1).shape, dtype=torch.int64, device=dev), table=M.StepTable(1, dev))
+            st["x1"].copy_(x_1, non_blocking=True); st["x2"].copy_(x_2, non_blocking=True); st["y"].copy_(target.reshape(-1), non_blocking=True)
+            torch.cuda.synchronize()
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g):
+                st["table"].n = 0
+                if training:
+                    st["out"], st["loss"] = self._train_step_eager(st["x1"], st["x2"], st["y"], st["table"], set_to_none=True)
+                else:
+                    st["out"], st["loss"] = self._eval_step_eager(st["x1"], st["x2"], st["y"], st["table"])
+            ent["g"] = g                                    # (capture does not execute: replay below runs this batch)
+        st = ent["static"]
+        st["x1"].copy_(x_1, non_blocking=True)
+        st["x2"].copy_(x_2, non_blocking=True)
+        st["y"].copy_(target.reshape(-1), non_blocking=True)
+        ent["g"].replay()
+        loss_slot, count_slot = table.slot()
+        loss_slot.copy_(st["table"].loss[:1])
+        count_slot.copy_(st["table"].counts[0])
+        return st["out"], st["loss"]
 
     def _forward_loss(self, x_1, x_2, target, training, table):
         model, dev = self.model, self.device
@@ -136,7 +197,18 @@ class StepRunner:
         return output, loss, dlogits
 
     def train_step(self, x_1, x_2, target, table):
-        self.optimizer.zero_grad()
+        done = self._graph_step(True, x_1, x_2, target, table)
+        return done if done is not None else self._train_step_eager(x_1, x_2, target, table)
+
+    def eval_step(self, x_1, x_2, target, table):
+        done = self._graph_step(False, x_1, x_2, target, table)
+        return done if done is not None else self._eval_step_eager(x_1, x_2, target, table)
+
+    def _train_step_eager(self, x_1, x_2, target, table, set_to_none=None):
+        if set_to_none is None:
+            self.optimizer.zero_grad()
+        else:
+            self.optimizer.zero_grad(set_to_none=set_to_none)
         output, loss, dlogits = self._forward_loss(x_1, x_2, target, True, table)
         deferred = output.is_cuda
         if deferred:
@@ -157,7 +229,7 @@ class StepRunner:
                 self.optimizer.external_tick = False
         return output, loss
 
-    def eval_step(self, x_1, x_2, target, table):
+    def _eval_step_eager(self, x_1, x_2, target, table):
         with torch.no_grad():
             output, loss, _ = self._forward_loss(x_1, x_2, target, False, table)
         return output, loss
@@ -190,8 +262,9 @@ def _pairs(loader):
 
 
 def fit_multimodal(model, train_loader, test_loader, device, cell_line, task, optimizer=None, num_epochs=100,
-                   patience=4, delta=0, verbose=True, checkpoint_path=None, precision=None):
-    """Train `model`, or reload it and its scores when `checkpoint_path` exists.
+                   patience=4, delta=0, verbose=True, checkpoint_path=None, precision=None, graph=None):
+    """Train `model`, or reload it and its scores when `checkpoint_path` exists.  `precision` / `graph` are this engine's
+    additions (see prepare_model / set_graph_steps); everything else is the reference's signature.
     Returns (AUPRC_train_scores, AUPRC_test_scores, F1_precision_recall_test_scores), one entry per epoch."""
     _check_names(cell_line, task)
     if checkpoint_path is not None and os.path.exists(checkpoint_path):
@@ -205,7 +278,7 @@ def fit_multimodal(model, train_loader, test_loader, device, cell_line, task, op
     AUPRC_train_scores, AUPRC_test_scores, F1_precision_recall_test_scores = [], [], []
     model = prepare_model(model, device, precision)
     early_stopping = M.EarlyStopping(patience=patience, delta=delta, verbose=True)
-    runner = StepRunner(model, optimizer, device)
+    runner = StepRunner(model, optimizer, device, graph=graph)
     cap = max(len(train_loader['FFNN']), len(test_loader['FFNN'])) + 2   # BalancePos sampler yields len+1 batches
     table = M.StepTable(cap, device)
 

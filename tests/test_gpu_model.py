@@ -173,6 +173,34 @@ def test_philox_training_step_bf16_runs_and_learns(ea):
     assert np.isfinite(losses).all() and np.mean(losses[-5:]) < np.mean(losses[:5]) - 0.02, losses
 
 
+@pytest.mark.parametrize("precision", ["bfloat16", "float32"])
+def test_graph_replayed_steps_equal_eager_steps(ea, precision):
+    """training.set_graph_steps: fit_multimodal replaying captured train / eval steps (one hipGraph per batch shape, ragged
+    last batch included) ends in bit-identical parameters, BatchNorm statistics and per-epoch scores as the eager loop."""
+    from embracenet_amd import optim, training
+    def run(graph):
+        model, trial, hp, F_in = build(ea, "small", "gr", torch.float32)
+        model.set_rng("philox", seed=11)
+        def mk(prefix, sizes):
+            bt = [model_batch(f"gr/{prefix}{k}", bs, F_in, 0.3) for k, bs in enumerate(sizes)]
+            t = lambda a: torch.from_numpy(a).float()
+            return {"FFNN": [(t(a), torch.from_numpy(y)) for a, b, y in bt], "CNN": [(t(b), torch.from_numpy(y)) for a, b, y in bt]}
+        opt = optim.Adam(model.parameters(), lr=1e-3, weight_decay=1e-4)
+        training.set_graph_steps(graph)
+        try:
+            res = training.fit_multimodal(model, mk("train", [64] * 5 + [24]), mk("test", [128] * 4), DEV, "A549",
+                                          "active_E_vs_inactive_E", optimizer=opt, num_epochs=3, patience=10,
+                                          verbose=False, precision=precision)
+        finally:
+            training.set_graph_steps(False)
+        return res, {k: v.detach().cpu().clone() for k, v in model.state_dict().items()}
+    (ra, sa), (rb, sb) = run(False), run(True)
+    assert ra[0] == rb[0] and ra[1] == rb[1]
+    assert np.array_equal(np.array(ra[2]), np.array(rb[2]))
+    for k in sa:
+        assert torch.equal(sa[k], sb[k]), k
+
+
 @pytest.mark.parametrize("i", range(2))
 def test_g10_inference_twin_matches_reference(ea, i, tmp_path):
     """Row f3: EmbraceNetMultimodal_NoTrain rebuilt from a harness-format checkpoint reproduces the reference's twin --
