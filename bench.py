@@ -186,6 +186,8 @@ def main():
     ap.add_argument("--roofline-only", action="store_true", help="only time the isolated kernels (used under rocprofv3 --pmc)")
     ap.add_argument("--packed-input", action="store_true",
                     help="stage the DNA windows as uint8 base codes (SURVEY 8 row f4) instead of the loader's [B,4,256] floats")
+    ap.add_argument("--sync-bn", action="store_true", help="N>1: BatchNorm statistics of the global batch (parity switch, "
+                    "dist.set_sync_batchnorm); default is local statistics")
     ap.add_argument("--split-graph", action="store_true", help="N>1: keep the all-reduce outside the captured graphs")
     ap.add_argument("--force-collectives", action="store_true",
                     help="run the N>1 code path (flat gradient buffer, all-reduce in the step) with a single rank")
@@ -207,6 +209,7 @@ def main():
     if args.force_collectives and world == 1 and not torch.distributed.is_initialized():
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         torch.distributed.init_process_group(args.backend or "nccl", init_method="tcp://127.0.0.1:29537", rank=0, world_size=1)
+    D.FORCE_COLLECTIVES = bool(args.force_collectives)
 
     if args.roofline_only:
         kern, dims = kernel_roofline(ea, wl, device)
@@ -218,6 +221,8 @@ def main():
                                     in_features_FFNN=Fin)
     model = training.prepare_model(model, device, wl["dtype"]).set_rng("philox", seed=2024, row0=rank * B)
     opt = optim.Adam(model.parameters(), lr=1e-3, weight_decay=1e-3)
+    if args.sync_bn:
+        D.set_sync_batchnorm(model)
     x1, x2, y = synth_batch(B, Fin, wl["pos"], device, 100 + rank)
     in_dt = model.compute_dtype or next(model.parameters()).dtype   # inputs staged in the compute dtype
     x1, x2 = x1.to(in_dt), (ea.functional.pack_onehot(x2) if args.packed_input else x2.to(in_dt))
@@ -342,6 +347,7 @@ def main():
                        "step": "zero_grad+fwd+weighted CE+bwd" + ("+allreduce" if world > 1 else "") + "+fused Adam",
                        "graph": bool(use_graph), "graph_mode": graph_mode,
                        "sequence_input": "uint8 base codes [B,256]" if args.packed_input else "one-hot [B,4,256] (loader format)", "rng": "philox (device-side modality dropout and selection)",
+                       "batchnorm": "global-batch statistics (all-reduced sums)" if (args.sync_bn and D.collectives_on()) else "local statistics per rank",
                        "final_loss": final_loss},
         }
         if world == 1 and not args.no_extras:

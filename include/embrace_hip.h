@@ -198,7 +198,17 @@ int emb_nadam_step_multi(void* const* params, const void* const* grads, void* co
  *                         In that mode the input may be staged as BASE CODES: x_codes != 0 -> x is
  *                         uint8[B][L] with 0-3 = the hot channel of the one-hot column (dataprepare.py:398-412 order) and
  *                         any other value = an all-zero column; the one-hot row is formed in LDS, the [B][4][L] float
- *                         tensor and its layout conversion never exist (8x less input traffic).  x_codes = 0 otherwise. */
+ *                         tensor and its layout conversion never exist (8x less input traffic).  x_codes = 0 otherwise.
+ *   bn_phase / bn_sums    BatchNorm statistics of the GLOBAL batch when the batch rows are sharded over processes
+ *                         (nn.BatchNorm1d at CNN_pre.py:41 normalises over the whole batch).  bn_phase = 0:
+ *                         one call, statistics of this call's rows (bn_sums ignored).  Otherwise the block is two calls
+ *                         with the same arguments around one SUM all-reduce of bn_sums (2*Cout+1 doubles, caller-owned):
+ *                           forward   phase 1: convolution + sums -> bn_sums = {sum y[c]}, {sum y[c]^2}, rows;
+ *                                     phase 2: mean / invstd / running statistics from bn_sums, then BN/ReLU/pool/dropout;
+ *                           backward  phase 1: dz + sums -> bn_sums = {sum dz[c]}, {sum dz[c]*xhat[c]}, rows; dgamma / dbeta
+ *                                     written (LOCAL sums: the gradient all-reduce adds them like any other gradient);
+ *                                     phase 2: dy from the all-reduced means, weight / bias / input gradients.
+ *                         Training mode only (eval uses the running statistics, nothing to exchange). */
 int64_t emb_convblock_workspace_bytes(int B, int L, int cin_pad, int Cout, int k, int dtype);
 int emb_ncl_to_nlc(const void* x, int src_dtype, void* out, int dst_dtype, int B, int C, int L, int Cpad,
                    emb_stream_t stream);
@@ -214,13 +224,13 @@ int emb_convblock_fwd(const void* x, const void* wpack, const void* bias, const 
                       void* running_mean, void* running_var, int training, double momentum, double eps,
                       float dropout_p, uint64_t seed, uint64_t step_val, const uint64_t* step_dev, int64_t row0,
                       int layer_id, void* y, void* stats, void* out, uint8_t* argmax, int out_ncl, void* workspace,
-                      int64_t workspace_bytes, int64_t* num_batches_tracked, int x_codes, int B, int L, int cin_pad,
-                      int Cout, int k, int dtype, emb_stream_t stream);
+                      int64_t workspace_bytes, int64_t* num_batches_tracked, int x_codes, int bn_phase, double* bn_sums,
+                      int B, int L, int cin_pad, int Cout, int k, int dtype, emb_stream_t stream);
 int emb_convblock_bwd(const void* dout, int dout_ncl, const uint8_t* argmax, const void* y, const void* stats,
                       const void* x, const void* wflip, const void* wpack, const void* bias, float dropout_p,
                       int training, void* dx, void* dW, void* dbias, void* dgamma, void* dbeta, void* dy,
-                      void* workspace, int64_t workspace_bytes, int x_codes, int B, int L, int Cin, int cin_pad,
-                      int Cout, int k, int dtype, emb_stream_t stream);
+                      void* workspace, int64_t workspace_bytes, int x_codes, int bn_phase, double* bn_sums, int B, int L,
+                      int Cin, int cin_pad, int Cout, int k, int dtype, emb_stream_t stream);
 int emb_convblock_needs_y(int B, int L, int cin_pad, int Cout, int k, int dtype);
 
 /* Slab reductions.  The weight-gradient kernels of emb_embrace_bwd / emb_linear_bwd / emb_mlp_bwd / emb_convblock_bwd write

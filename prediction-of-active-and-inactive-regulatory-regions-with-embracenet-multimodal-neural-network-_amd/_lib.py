@@ -49,8 +49,8 @@ SIGNATURES = {
     "emb_ncl_to_nlc": [_vp, _i, _vp, _i, _i, _i, _i, _i, _vp],
     "emb_conv_pack_weight": [_vp, _vp, _vp, _i, _i, _i, _i, _i, _vp],
     "emb_convblock_fwd": [_vp] * 7 + [_i, _d, _d, _f, _u64, _u64, _vp, _i64, _i, _vp, _vp, _vp, _vp, _i, _vp, _i64, _vp,
-                                     _i, _i, _i, _i, _i, _i, _i, _vp],
-    "emb_convblock_bwd": [_vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _f, _i] + [_vp] * 7 + [_i64, _i, _i, _i, _i, _i, _i, _i, _i, _vp],
+                                     _i, _i, _vp, _i, _i, _i, _i, _i, _i, _vp],
+    "emb_convblock_bwd": [_vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _f, _i] + [_vp] * 7 + [_i64, _i, _i, _vp, _i, _i, _i, _i, _i, _i, _i, _vp],
     "emb_conv_pack_register": [_vp, _vp, _vp, _i, _i, _i, _i],
     "emb_conv_pack_unregister": [_vp],
     "emb_reduce_defer": [_i],

@@ -144,8 +144,10 @@ static int launch_conv_gemm(const void* x, const void* w, const void* bias, void
 
 // ------------------------------------------------------------------------------- BN statistics
 // stats[0..3][C] = mean, invstd, scale = gamma*invstd, shift = beta - mean*scale   (P-typed)
-template <typename P>
-__global__ __launch_bounds__(256) void bn_finalize_kernel(const P* __restrict__ partial, int tiles_m, int C, double count,
+// `count_dev` (global-batch statistics, emb_convblock_fwd bn_phase 2): the row count behind the sums, on the device.
+template <typename P, typename PP>
+__global__ __launch_bounds__(256) void bn_finalize_kernel(const PP* __restrict__ partial, int tiles_m, int C, double count,
+                                                          const double* __restrict__ count_dev,
                                                           const P* __restrict__ gamma, const P* __restrict__ beta,
                                                           P* __restrict__ running_mean, P* __restrict__ running_var,
                                                           int training, double momentum, double eps, P* __restrict__ stats,
@@ -153,6 +155,7 @@ __global__ __launch_bounds__(256) void bn_finalize_kernel(const P* __restrict__ 
   __shared__ double sa[256], sb[256];
   const int c = blockIdx.x, tid = threadIdx.x;
   double mean, var;
+  if (count_dev != nullptr) count = *count_dev;
   if (training) {
     double a = 0, b = 0;
 #pragma unroll 4
@@ -370,11 +373,16 @@ __global__ __launch_bounds__(256) void bn_bwd_dz_kernel(const T* __restrict__ do
 }
 
 // finalise dgamma / dbeta and the two per-channel means the apply pass needs: coef[0][c] = mean(dz), coef[1][c] = mean(dz*xhat)
-template <typename P>
-__global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(const P* __restrict__ bpart, int nblk, int C, double count,
-                                                              P* __restrict__ dgamma, P* __restrict__ dbeta, P* __restrict__ coef) {
+// Global-batch statistics (bn_phase): phase 1 passes `sums` (raw double sums out, coef untouched), phase 2 passes the
+// all-reduced sums as `bpart` (PP = double, nblk = 1), `count_dev` and no dgamma / dbeta (those stay LOCAL sums: the
+// data-parallel gradient reduction adds them over ranks like every other parameter gradient).
+template <typename P, typename PP>
+__global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(const PP* __restrict__ bpart, int nblk, int C, double count,
+                                                              const double* __restrict__ count_dev, P* __restrict__ dgamma,
+                                                              P* __restrict__ dbeta, P* __restrict__ coef, double* __restrict__ sums) {
   __shared__ double sa[256], sb[256];
   const int c = blockIdx.x, tid = threadIdx.x;
+  if (count_dev != nullptr) count = *count_dev;
   double a = 0, b = 0;
 #pragma unroll 4
   for (int t = tid; t < nblk; t += 256) {
@@ -392,10 +400,48 @@ __global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(const P* __restric
     __syncthreads();
   }
   if (tid == 0) {
-    dbeta[c] = (P)sa[0];
-    dgamma[c] = (P)sb[0];
-    coef[c] = (P)(sa[0] / count);
-    coef[C + c] = (P)(sb[0] / count);
+    if (dbeta != nullptr) {
+      dbeta[c] = (P)sa[0];
+      dgamma[c] = (P)sb[0];
+    }
+    if (sums != nullptr) {
+      sums[c] = sa[0];
+      sums[C + c] = sb[0];
+      if (c == 0) sums[2 * C] = count;
+    } else {
+      coef[c] = (P)(sa[0] / count);
+      coef[C + c] = (P)(sb[0] / count);
+    }
+  }
+}
+
+// phase 1 of the forward with global-batch statistics: per-tile partial sums -> sums[0..C) = sum x, [C..2C) = sum x^2,
+// sums[2C] = rows behind them (all double; the caller all-reduces the 2C+1 values over the ranks)
+template <typename P>
+__global__ __launch_bounds__(256) void bn_sums_kernel(const P* __restrict__ partial, int tiles_m, int C, double count,
+                                                      double* __restrict__ sums) {
+  __shared__ double sa[256], sb[256];
+  const int c = blockIdx.x, tid = threadIdx.x;
+  double a = 0, b = 0;
+#pragma unroll 4
+  for (int t = tid; t < tiles_m; t += 256) {
+    a += (double)partial[((long)t * 2 + 0) * C + c];
+    b += (double)partial[((long)t * 2 + 1) * C + c];
+  }
+  sa[tid] = a;
+  sb[tid] = b;
+  __syncthreads();
+  for (int s = 128; s > 0; s >>= 1) {
+    if (tid < s) {
+      sa[tid] += sa[tid + s];
+      sb[tid] += sb[tid + s];
+    }
+    __syncthreads();
+  }
+  if (tid == 0) {
+    sums[c] = sa[0];
+    sums[C + c] = sb[0];
+    if (c == 0) sums[2 * C] = count;
   }
 }
 
@@ -537,8 +583,8 @@ template <typename T>
 static int convblock_fwd(const void* x, const void* wpack, const void* bias, const void* gamma, const void* beta, void* rmean,
                          void* rvar, int training, double momentum, double eps, float drop_p, uint64_t seed, uint64_t step_val,
                          const uint64_t* step_dev, int64_t row0, int layer_id, void* y, void* stats, void* out, uint8_t* argmax,
-                         int out_ncl, void* ws, int64_t ws_bytes, void* nbt, int x_codes, int B, int L, int cin_pad, int Cout, int k,
-                         hipStream_t s) {
+                         int out_ncl, void* ws, int64_t ws_bytes, void* nbt, int x_codes, int bn_phase, double* bn_sums, int B, int L,
+                         int cin_pad, int Cout, int k, hipStream_t s) {
   using P = typename AccOf<T>::type;
   constexpr int VEC = Elem<T>::VEC;
   const ConvWs w = conv_workspace<T>(B, L, cin_pad, Cout, k);
@@ -551,27 +597,46 @@ static int convblock_fwd(const void* x, const void* wpack, const void* bias, con
     EMB_CHECK_ARG(conv_first_supported(dtype_code<T>(), B, L, cin_pad, Cout, k),
                   "emb_convblock_fwd: y may only be NULL when emb_convblock_needs_y() returns 0");
     int rows = 0;
-    if (training) {
+    if (training && bn_phase != 2) {
       const int rc0 = conv_first_stats(x, x_codes, wpack, bias, ws, &rows, B, L, Cout, k, s);
       if (rc0 != EMB_OK) return rc0 == 1 ? EMB_ERR_ARG : rc0;
     }
-    bn_finalize_kernel<P><<<Cout, 256, 0, s>>>((const P*)ws, rows, Cout, (double)R, (const P*)gamma, (const P*)beta, (P*)rmean,
-                                             (P*)rvar, training, momentum, eps, (P*)stats, (long long*)nbt);
+    if (bn_phase == 1) {
+      bn_sums_kernel<P><<<Cout, 256, 0, s>>>((const P*)ws, rows, Cout, (double)R, bn_sums);
+      EMB_CHECK_LAUNCH();
+      return EMB_OK;
+    }
+    if (bn_phase == 2)
+      bn_finalize_kernel<P, double><<<Cout, 256, 0, s>>>(bn_sums, 1, Cout, 0.0, bn_sums + 2 * Cout, (const P*)gamma, (const P*)beta,
+                                                        (P*)rmean, (P*)rvar, training, momentum, eps, (P*)stats, (long long*)nbt);
+    else
+      bn_finalize_kernel<P, P><<<Cout, 256, 0, s>>>((const P*)ws, rows, Cout, (double)R, nullptr, (const P*)gamma, (const P*)beta,
+                                                   (P*)rmean, (P*)rvar, training, momentum, eps, (P*)stats, (long long*)nbt);
     EMB_CHECK_LAUNCH();
     const int rc1 = conv_first_apply(x, x_codes, wpack, bias, stats, out, argmax, out_ncl, drop_p, seed, step_val, step_dev, row0, layer_id, B, L,
                                      Cout, k, s);
     return rc1 == 1 ? EMB_ERR_ARG : rc1;
   }
-  int tiles_m = conv_tiling(B, L, pad).tiles_m;
-  int rc = launch_conv_direct(dtype_code<T>(), true, x, wpack, bias, y, ws, &tiles_m, B, L, cin_pad, KK, Cout, pad, s);
-  if (rc == 1) {   // activation tile does not fit in LDS: generic GEMM on the im2col view
-    if (Cout >= 64) rc = launch_conv_gemm<typename ConvCfg<T>::F64, true>(x, wpack, bias, y, ws, R, L, cin_pad, KK, Cout, pad, s);
-    else rc = launch_conv_gemm<typename ConvCfg<T>::F32, true>(x, wpack, bias, y, ws, R, L, cin_pad, KK, Cout, pad, s);
-    tiles_m = cdiv(R, Cout >= 64 ? ConvCfg<T>::F64::BM : ConvCfg<T>::F32::BM);
+  if (bn_phase != 2) {   // the convolution (stored) and its per-tile channel sums
+    int tiles_m = conv_tiling(B, L, pad).tiles_m;
+    int rc = launch_conv_direct(dtype_code<T>(), true, x, wpack, bias, y, ws, &tiles_m, B, L, cin_pad, KK, Cout, pad, s);
+    if (rc == 1) {   // activation tile does not fit in LDS: generic GEMM on the im2col view
+      if (Cout >= 64) rc = launch_conv_gemm<typename ConvCfg<T>::F64, true>(x, wpack, bias, y, ws, R, L, cin_pad, KK, Cout, pad, s);
+      else rc = launch_conv_gemm<typename ConvCfg<T>::F32, true>(x, wpack, bias, y, ws, R, L, cin_pad, KK, Cout, pad, s);
+      tiles_m = cdiv(R, Cout >= 64 ? ConvCfg<T>::F64::BM : ConvCfg<T>::F32::BM);
+    }
+    if (rc != EMB_OK) return rc;
+    if (bn_phase == 1) {
+      bn_sums_kernel<P><<<Cout, 256, 0, s>>>((const P*)ws, tiles_m, Cout, (double)R, bn_sums);
+      EMB_CHECK_LAUNCH();
+      return EMB_OK;
+    }
+    bn_finalize_kernel<P, P><<<Cout, 256, 0, s>>>((const P*)ws, tiles_m, Cout, (double)R, nullptr, (const P*)gamma, (const P*)beta,
+                                                 (P*)rmean, (P*)rvar, training, momentum, eps, (P*)stats, (long long*)nbt);
+  } else {
+    bn_finalize_kernel<P, double><<<Cout, 256, 0, s>>>(bn_sums, 1, Cout, 0.0, bn_sums + 2 * Cout, (const P*)gamma, (const P*)beta,
+                                                      (P*)rmean, (P*)rvar, training, momentum, eps, (P*)stats, (long long*)nbt);
   }
-  if (rc != EMB_OK) return rc;
-  bn_finalize_kernel<P><<<Cout, 256, 0, s>>>((const P*)ws, tiles_m, Cout, (double)R, (const P*)gamma, (const P*)beta, (P*)rmean,
-                                           (P*)rvar, training, momentum, eps, (P*)stats, (long long*)nbt);
   EMB_CHECK_LAUNCH();
   const long total = (long)B * Lp * (Cout / VEC);
   const int grid = (int)((total + 255) / 256);
@@ -586,8 +651,8 @@ static int convblock_fwd(const void* x, const void* wpack, const void* bias, con
 template <typename T>
 static int convblock_bwd(const void* dout, int dout_ncl, const uint8_t* argmax, const void* y, const void* stats, const void* x,
                          const void* wflip, const void* wpack, const void* bias, float drop_p, int training, void* dx, void* dW,
-                         void* dbias, void* dgamma, void* dbeta, void* dy, void* ws, int64_t ws_bytes, int x_codes, int B, int L,
-                         int Cin, int cin_pad, int Cout, int k, hipStream_t s) {
+                         void* dbias, void* dgamma, void* dbeta, void* dy, void* ws, int64_t ws_bytes, int x_codes, int bn_phase,
+                         double* bn_sums, int B, int L, int Cin, int cin_pad, int Cout, int k, hipStream_t s) {
   using P = typename AccOf<T>::type;
   using CW = typename ConvCfg<T>::W;
   constexpr int VEC = Elem<T>::VEC;
@@ -606,11 +671,19 @@ static int convblock_bwd(const void* dout, int dout_ncl, const uint8_t* argmax, 
     const int nb = conv_first_blocks(B, L, cin_pad, Cout, k);
     EMB_CHECK_ARG((size_t)nb * 2 * Cout * sizeof(P) <= w.bwd_partial && (size_t)nb * Cout * (KK + 1) * sizeof(P) <= w.slab,
                   "emb_convblock_bwd: workspace layout too small for the fused first block");
-    int rows = 0, S = 0;
-    int rc = conv_first_bwd_sums(dout, dout_ncl, argmax, x, x_codes, wpack, bias, stats, keep_scale, bpart, &rows, B, L, Cout, k, s);
-    if (rc != EMB_OK) return rc == 1 ? EMB_ERR_ARG : rc;
-    bn_bwd_finalize_kernel<P><<<Cout, 256, 0, s>>>(bpart, rows, Cout, (double)R, (P*)dgamma, (P*)dbeta, coef);
-    EMB_CHECK_LAUNCH();
+    int rows = 0, S = 0, rc = EMB_OK;
+    if (bn_phase != 2) {
+      rc = conv_first_bwd_sums(dout, dout_ncl, argmax, x, x_codes, wpack, bias, stats, keep_scale, bpart, &rows, B, L, Cout, k, s);
+      if (rc != EMB_OK) return rc == 1 ? EMB_ERR_ARG : rc;
+      bn_bwd_finalize_kernel<P, P><<<Cout, 256, 0, s>>>(bpart, rows, Cout, (double)R, nullptr, (P*)dgamma, (P*)dbeta, coef,
+                                                       bn_phase == 1 ? bn_sums : nullptr);
+      EMB_CHECK_LAUNCH();
+      if (bn_phase == 1) return EMB_OK;
+    } else {
+      bn_bwd_finalize_kernel<P, double><<<Cout, 256, 0, s>>>(bn_sums, 1, Cout, 0.0, bn_sums + 2 * Cout, (P*)nullptr, (P*)nullptr, coef,
+                                                            nullptr);
+      EMB_CHECK_LAUNCH();
+    }
     rc = conv_first_bwd_wgrad(dout, dout_ncl, argmax, x, x_codes, wpack, bias, stats, coef, keep_scale, training, slab, &S, B, L, Cout, k, s);
     if (rc != EMB_OK) return rc == 1 ? EMB_ERR_ARG : rc;
     ReduceJob j{};   // slabs -> dW (torch layout, real channels) / dbias, slices summed in fixed order (reduce.hip)
@@ -621,17 +694,25 @@ static int convblock_bwd(const void* dout, int dout_ncl, const uint8_t* argmax, 
   {   // dgamma / dbeta are defined in eval mode too (x-hat then uses the running statistics)
     const int TT = w.rows_per_block, tiles_per_seq = cdiv(L, TT);
     const int TY = 256 / (Cout / VEC);
-    size_t sm = (size_t)(TT / 2 + 5) * Cout * (sizeof(T) + 1);
-    const size_t sm_red = (size_t)TY * 2 * Cout * sizeof(P);
-    if (sm_red > sm) sm = sm_red;
-    sm = (sm + 15) & ~(size_t)15;
-    if (dout_ncl)
-      bn_bwd_dz_kernel<T, true><<<w.nblk_bwd, 256, sm, s>>>((const T*)dout, argmax, (const T*)y, (const P*)stats, (T*)dy, bpart, L, Lp, Cout, keep_scale, TT, tiles_per_seq);
-    else
-      bn_bwd_dz_kernel<T, false><<<w.nblk_bwd, 256, sm, s>>>((const T*)dout, argmax, (const T*)y, (const P*)stats, (T*)dy, bpart, L, Lp, Cout, keep_scale, TT, tiles_per_seq);
-    EMB_CHECK_LAUNCH();
-    bn_bwd_finalize_kernel<P><<<Cout, 256, 0, s>>>(bpart, w.nblk_bwd, Cout, (double)R, (P*)dgamma, (P*)dbeta, coef);
-    EMB_CHECK_LAUNCH();
+    if (bn_phase != 2) {   // dz into the dy buffer + the per-block channel sums
+      size_t sm = (size_t)(TT / 2 + 5) * Cout * (sizeof(T) + 1);
+      const size_t sm_red = (size_t)TY * 2 * Cout * sizeof(P);
+      if (sm_red > sm) sm = sm_red;
+      sm = (sm + 15) & ~(size_t)15;
+      if (dout_ncl)
+        bn_bwd_dz_kernel<T, true><<<w.nblk_bwd, 256, sm, s>>>((const T*)dout, argmax, (const T*)y, (const P*)stats, (T*)dy, bpart, L, Lp, Cout, keep_scale, TT, tiles_per_seq);
+      else
+        bn_bwd_dz_kernel<T, false><<<w.nblk_bwd, 256, sm, s>>>((const T*)dout, argmax, (const T*)y, (const P*)stats, (T*)dy, bpart, L, Lp, Cout, keep_scale, TT, tiles_per_seq);
+      EMB_CHECK_LAUNCH();
+      bn_bwd_finalize_kernel<P, P><<<Cout, 256, 0, s>>>(bpart, w.nblk_bwd, Cout, (double)R, nullptr, (P*)dgamma, (P*)dbeta, coef,
+                                                       bn_phase == 1 ? bn_sums : nullptr);
+      EMB_CHECK_LAUNCH();
+      if (bn_phase == 1) return EMB_OK;
+    } else {
+      bn_bwd_finalize_kernel<P, double><<<Cout, 256, 0, s>>>(bn_sums, 1, Cout, 0.0, bn_sums + 2 * Cout, (P*)nullptr, (P*)nullptr, coef,
+                                                            nullptr);
+      EMB_CHECK_LAUNCH();
+    }
     const int rpb = TY * 8;   // rows per block of the elementwise pass
     bn_bwd_affine_kernel<T><<<cdiv(R, rpb), 256, 0, s>>>((const T*)y, (const P*)stats, coef, (T*)dy, R, Cout, training, rpb);
     EMB_CHECK_LAUNCH();
@@ -733,17 +814,19 @@ extern "C" int emb_convblock_fwd(const void* x, const void* wpack, const void* b
                                  void* running_mean, void* running_var, int training, double momentum, double eps,
                                  float dropout_p, uint64_t seed, uint64_t step_val, const uint64_t* step_dev, int64_t row0,
                                  int layer_id, void* y, void* stats, void* out, uint8_t* argmax, int out_ncl, void* workspace,
-                                 int64_t workspace_bytes, int64_t* num_batches_tracked, int x_codes, int B, int L, int cin_pad,
-                                 int Cout, int k, int dtype, emb_stream_t stream) {
+                                 int64_t workspace_bytes, int64_t* num_batches_tracked, int x_codes, int bn_phase, double* bn_sums,
+                                 int B, int L, int cin_pad, int Cout, int k, int dtype, emb_stream_t stream) {
   EMB_CHECK_ARG(x && wpack && bias && gamma && beta && running_mean && running_var && stats && out && argmax && workspace,
                 "emb_convblock_fwd: null pointer");
   EMB_CHECK_ARG(B > 0 && L > 0 && cin_pad > 0 && Cout > 0 && k > 0 && (k & 1), "emb_convblock_fwd: bad dims");
   EMB_CHECK_ARG(dropout_p >= 0.f && dropout_p < 1.f, "emb_convblock_fwd: dropout_p must be in [0,1)");
+  EMB_CHECK_ARG(bn_phase == 0 || ((bn_phase == 1 || bn_phase == 2) && bn_sums != nullptr && training),
+                "emb_convblock_fwd: bn_phase is 0, or 1 / 2 with bn_sums in training mode");
   hipStream_t s = (hipStream_t)stream;
   switch (dtype) {
-    case EMB_F32: return convblock_fwd<float>(x, wpack, bias, gamma, beta, running_mean, running_var, training, momentum, eps, dropout_p, seed, step_val, step_dev, row0, layer_id, y, stats, out, argmax, out_ncl, workspace, workspace_bytes, num_batches_tracked, x_codes, B, L, cin_pad, Cout, k, s);
-    case EMB_BF16: return convblock_fwd<__bf16>(x, wpack, bias, gamma, beta, running_mean, running_var, training, momentum, eps, dropout_p, seed, step_val, step_dev, row0, layer_id, y, stats, out, argmax, out_ncl, workspace, workspace_bytes, num_batches_tracked, x_codes, B, L, cin_pad, Cout, k, s);
-    case EMB_F64: return convblock_fwd<double>(x, wpack, bias, gamma, beta, running_mean, running_var, training, momentum, eps, dropout_p, seed, step_val, step_dev, row0, layer_id, y, stats, out, argmax, out_ncl, workspace, workspace_bytes, num_batches_tracked, x_codes, B, L, cin_pad, Cout, k, s);
+    case EMB_F32: return convblock_fwd<float>(x, wpack, bias, gamma, beta, running_mean, running_var, training, momentum, eps, dropout_p, seed, step_val, step_dev, row0, layer_id, y, stats, out, argmax, out_ncl, workspace, workspace_bytes, num_batches_tracked, x_codes, bn_phase, bn_sums, B, L, cin_pad, Cout, k, s);
+    case EMB_BF16: return convblock_fwd<__bf16>(x, wpack, bias, gamma, beta, running_mean, running_var, training, momentum, eps, dropout_p, seed, step_val, step_dev, row0, layer_id, y, stats, out, argmax, out_ncl, workspace, workspace_bytes, num_batches_tracked, x_codes, bn_phase, bn_sums, B, L, cin_pad, Cout, k, s);
+    case EMB_F64: return convblock_fwd<double>(x, wpack, bias, gamma, beta, running_mean, running_var, training, momentum, eps, dropout_p, seed, step_val, step_dev, row0, layer_id, y, stats, out, argmax, out_ncl, workspace, workspace_bytes, num_batches_tracked, x_codes, bn_phase, bn_sums, B, L, cin_pad, Cout, k, s);
   }
   set_error("emb_convblock_fwd: unsupported dtype %d", dtype);
   return EMB_ERR_DTYPE;
@@ -756,17 +839,19 @@ extern "C" int emb_convblock_needs_y(int B, int L, int cin_pad, int Cout, int k,
 extern "C" int emb_convblock_bwd(const void* dout, int dout_ncl, const uint8_t* argmax, const void* y, const void* stats,
                                  const void* x, const void* wflip, const void* wpack, const void* bias, float dropout_p,
                                  int training, void* dx, void* dW, void* dbias, void* dgamma, void* dbeta, void* dy, void* workspace,
-                                 int64_t workspace_bytes, int x_codes, int B, int L, int Cin, int cin_pad, int Cout, int k,
-                                 int dtype, emb_stream_t stream) {
+                                 int64_t workspace_bytes, int x_codes, int bn_phase, double* bn_sums, int B, int L, int Cin, int cin_pad,
+                                 int Cout, int k, int dtype, emb_stream_t stream) {
   EMB_CHECK_ARG(dout && argmax && stats && x && dW && dbias && dgamma && dbeta && workspace && (y == nullptr || dy != nullptr),
                 "emb_convblock_bwd: null pointer");
   EMB_CHECK_ARG(dx == nullptr || wflip != nullptr, "emb_convblock_bwd: wflip is required when dx is requested");
+  EMB_CHECK_ARG(bn_phase == 0 || ((bn_phase == 1 || bn_phase == 2) && bn_sums != nullptr && training),
+                "emb_convblock_bwd: bn_phase is 0, or 1 / 2 with bn_sums in training mode");
   EMB_CHECK_ARG(B > 0 && L > 0 && Cin > 0 && cin_pad >= Cin && Cout > 0 && k > 0 && (k & 1), "emb_convblock_bwd: bad dims");
   hipStream_t s = (hipStream_t)stream;
   switch (dtype) {
-    case EMB_F32: return convblock_bwd<float>(dout, dout_ncl, argmax, y, stats, x, wflip, wpack, bias, dropout_p, training, dx, dW, dbias, dgamma, dbeta, dy, workspace, workspace_bytes, x_codes, B, L, Cin, cin_pad, Cout, k, s);
-    case EMB_BF16: return convblock_bwd<__bf16>(dout, dout_ncl, argmax, y, stats, x, wflip, wpack, bias, dropout_p, training, dx, dW, dbias, dgamma, dbeta, dy, workspace, workspace_bytes, x_codes, B, L, Cin, cin_pad, Cout, k, s);
-    case EMB_F64: return convblock_bwd<double>(dout, dout_ncl, argmax, y, stats, x, wflip, wpack, bias, dropout_p, training, dx, dW, dbias, dgamma, dbeta, dy, workspace, workspace_bytes, x_codes, B, L, Cin, cin_pad, Cout, k, s);
+    case EMB_F32: return convblock_bwd<float>(dout, dout_ncl, argmax, y, stats, x, wflip, wpack, bias, dropout_p, training, dx, dW, dbias, dgamma, dbeta, dy, workspace, workspace_bytes, x_codes, bn_phase, bn_sums, B, L, Cin, cin_pad, Cout, k, s);
+    case EMB_BF16: return convblock_bwd<__bf16>(dout, dout_ncl, argmax, y, stats, x, wflip, wpack, bias, dropout_p, training, dx, dW, dbias, dgamma, dbeta, dy, workspace, workspace_bytes, x_codes, bn_phase, bn_sums, B, L, Cin, cin_pad, Cout, k, s);
+    case EMB_F64: return convblock_bwd<double>(dout, dout_ncl, argmax, y, stats, x, wflip, wpack, bias, dropout_p, training, dx, dW, dbias, dgamma, dbeta, dy, workspace, workspace_bytes, x_codes, bn_phase, bn_sums, B, L, Cin, cin_pad, Cout, k, s);
   }
   set_error("emb_convblock_bwd: unsupported dtype %d", dtype);
   return EMB_ERR_DTYPE;

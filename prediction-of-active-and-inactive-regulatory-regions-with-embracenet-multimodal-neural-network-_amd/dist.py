@@ -10,7 +10,8 @@ sharded is implemented here:
      fully connected 8-GPU xGMI mesh, so ONE flat bucket);
   3. the modality-dropout gate and every selection uniform are keyed on (seed, step, GLOBAL row), so
      the sampled index tensor does not depend on the number of ranks;
-  4. BatchNorm uses local statistics (as torch DDP does) -- documented deviation, SURVEY 8e(2).
+  4. BatchNorm: local statistics by default (as torch DDP); `set_sync_batchnorm(model)` switches the sequence
+     pre-network to statistics of the GLOBAL batch (the single-process result) -- SURVEY 8e(2).
 """
 import os
 
@@ -57,6 +58,31 @@ def allreduce_counts(class_counts):
     if world_size() > 1:
         dist.all_reduce(class_counts, op=dist.ReduceOp.SUM)
     return class_counts
+
+
+FORCE_COLLECTIVES = False    # rehearsal: issue the collectives with a single rank too (bench.py --force-collectives)
+
+
+def collectives_on():
+    return world_size() > 1 or (FORCE_COLLECTIVES and dist.is_initialized())
+
+
+def allreduce_sum_(t):
+    """SUM a device vector over the ranks in place (BatchNorm sums of the global batch, functional._ConvStackFn)."""
+    if collectives_on():
+        dist.all_reduce(t, op=dist.ReduceOp.SUM)
+    return t
+
+
+def set_sync_batchnorm(model, enable=True):
+    """Parity switch for data-parallel runs: every CNN_pre inside `model` takes its BatchNorm statistics (and the two
+    means of the BatchNorm backward) over the global batch instead of the rank's shard."""
+    n = 0
+    for m in model.modules():
+        if hasattr(m, "sync_batchnorm"):
+            m.sync_batchnorm = bool(enable)
+            n += 1
+    return n
 
 
 class GradBucket:

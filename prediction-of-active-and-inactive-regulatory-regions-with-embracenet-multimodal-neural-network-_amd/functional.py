@@ -479,11 +479,14 @@ def pool_out_len(L):
 
 
 class _ConvStackFn(torch.autograd.Function):
-    """args: x [B,C,L], training, rng, T, meta (tuple of per-layer dicts: k, drop_p, momentum, eps, layer_id), then per
-    layer: conv.weight, conv.bias, bn.weight, bn.bias, bn.running_mean, bn.running_var."""
+    """args: x [B,C,L], training, rng, T, meta (tuple of per-layer dicts: k, drop_p, momentum, eps, layer_id), bn_sync, then
+    per layer: conv.weight, conv.bias, bn.weight, bn.bias, bn.running_mean, bn.running_var.
+    bn_sync: None, or a callable that SUM-all-reduces a float64 device vector in place over the data-parallel ranks: the
+    BatchNorm statistics (forward) and the two BN-backward means then come from the GLOBAL batch (include/embrace_hip.h,
+    bn_phase), one exchange of 2*Cout+1 doubles per block and direction."""
 
     @staticmethod
-    def forward(ctx, x, training, rng, T, meta, *tensors):
+    def forward(ctx, x, training, rng, T, meta, bn_sync, *tensors):
         _lib.require_cuda(x)
         L_ = _lib.lib()
         P = PARAM_DTYPE[T]
@@ -527,22 +530,28 @@ class _ConvStackFn(torch.autograd.Function):
             argmax = torch.empty(B, Lp, Cout, dtype=torch.uint8, device=dev)
             nbytes = L_.emb_convblock_workspace_bytes(B, L, cin_pad, Cout, k, code)
             ws = _workspace(dev, nbytes, f"conv{i}")
-            check(L_.emb_convblock_fwd(ptr(cur), ptr(wpack), ptr(b.detach()), ptr(g.detach()), ptr(beta.detach()), ptr(rmean),
-                                       ptr(rvar), int(training), float(m["momentum"]), float(m["eps"]), float(m["drop_p"]),
-                                       rng.seed, rng.step_val, ptr(rng.step_dev), rng.row0, int(m["layer_id"]), ptr(y),
-                                       ptr(stats), ptr(out), ptr(argmax), int(last), ptr(ws), ws.numel(), ptr(nbt),
-                                       x_codes if i == 0 else 0, B, L, cin_pad, Cout, k, code, stream()), "emb_convblock_fwd")
+            sync = bn_sync if training else None
+            sums = torch.empty(2 * Cout + 1, dtype=torch.float64, device=dev) if sync is not None else None
+            for phase in ((1, 2) if sync is not None else (0,)):
+                check(L_.emb_convblock_fwd(ptr(cur), ptr(wpack), ptr(b.detach()), ptr(g.detach()), ptr(beta.detach()), ptr(rmean),
+                                           ptr(rvar), int(training), float(m["momentum"]), float(m["eps"]), float(m["drop_p"]),
+                                           rng.seed, rng.step_val, ptr(rng.step_dev), rng.row0, int(m["layer_id"]), ptr(y),
+                                           ptr(stats), ptr(out), ptr(argmax), int(last), ptr(ws), ws.numel(), ptr(nbt),
+                                           x_codes if i == 0 else 0, phase, ptr(sums), B, L, cin_pad, Cout, k, code, stream()),
+                      "emb_convblock_fwd")
+                if phase == 1:
+                    sync(sums)                                       # {sum y, sum y^2, rows} of the shard -> of the global batch
             saved += [cur, y if y is not None else stats, stats, argmax, wflip if wflip is not None else stats, wpack, b.detach()]
             shapes.append((L, Cin, cin_pad, Cout, k, float(m["drop_p"]), fused))
             cur, L, cin_pad = out, Lp, Cout
         ctx.save_for_backward(*saved)
-        ctx.cfg = (T, int(training), B, shapes, x_codes)
+        ctx.cfg = (T, int(training), B, shapes, x_codes, bn_sync if training else None)
         ctx.sinks = tuple(grad_sink(tensors[6 * i + j], P) for i in range(n_layers) for j in range(4))
         return cur.reshape(B, -1)
 
     @staticmethod
     def backward(ctx, dout):
-        T, training, B, shapes, x_codes = ctx.cfg
+        T, training, B, shapes, x_codes, sync = ctx.cfg
         P = PARAM_DTYPE[T]
         L_ = _lib.lib()
         code = DTYPE_CODE[T]
@@ -561,15 +570,18 @@ class _ConvStackFn(torch.autograd.Function):
             db, dgam, dbeta = (_out(sk[j], (Cout,), P, dev) for j in (1, 2, 3))
             nbytes = L_.emb_convblock_workspace_bytes(B, L, cin_pad, Cout, k, code)
             ws = _workspace(dev, nbytes, f"conv{i}")
-            check(L_.emb_convblock_bwd(ptr(g), int(last), ptr(argmax), None if fused else ptr(y), ptr(stats), ptr(xin),
-                                       ptr(wflip) if i > 0 else None, ptr(wpack), ptr(bias), drop_p, training, ptr(dx), ptr(dW),
-                                       ptr(db), ptr(dgam),
-                                       ptr(dbeta), ptr(dy), ptr(ws), ws.numel(), x_codes if i == 0 else 0, B, L, Cin, cin_pad, Cout,
-                                       k, code, stream()),
-                  "emb_convblock_bwd")
+            sums = torch.empty(2 * Cout + 1, dtype=torch.float64, device=dev) if sync is not None else None
+            for phase in ((1, 2) if sync is not None else (0,)):
+                check(L_.emb_convblock_bwd(ptr(g), int(last), ptr(argmax), None if fused else ptr(y), ptr(stats), ptr(xin),
+                                           ptr(wflip) if i > 0 else None, ptr(wpack), ptr(bias), drop_p, training, ptr(dx),
+                                           ptr(dW), ptr(db), ptr(dgam), ptr(dbeta), ptr(dy), ptr(ws), ws.numel(),
+                                           x_codes if i == 0 else 0, phase, ptr(sums), B, L, Cin, cin_pad, Cout, k, code, stream()),
+                      "emb_convblock_bwd")
+                if phase == 1:
+                    sync(sums)                                       # {sum dz, sum dz*xhat, rows} -> of the global batch
             grads[6 * i:6 * i + 4] = [None if sk[j] is not None else g_ for j, g_ in enumerate((dW, db, dgam, dbeta))]
             g = dx
-        return (None, None, None, None, None, *grads)
+        return (None, None, None, None, None, None, *grads)
 
 
 def pack_onehot(x):
@@ -585,9 +597,10 @@ def pack_onehot(x):
     return torch.where(hot.any(1), codes, torch.full_like(codes, 4)).contiguous()
 
 
-def conv_stack(x, layers, training, rng=None, compute_dtype=None):
+def conv_stack(x, layers, training, rng=None, compute_dtype=None, bn_sync=None):
     """layers: list of dicts with conv (nn.Conv1d), bn (nn.BatchNorm1d), drop_p, layer_id.
-    x: [B, C, L] float windows, or [B, L] uint8 base codes from `pack_onehot`."""
+    x: [B, C, L] float windows, or [B, L] uint8 base codes from `pack_onehot`.
+    bn_sync: see _ConvStackFn (BatchNorm statistics of the global batch under data parallelism)."""
     T = compute_dtype or layers[0]["conv"].weight.dtype
     meta, tensors = [], []
     for ly in layers:
@@ -596,4 +609,4 @@ def conv_stack(x, layers, training, rng=None, compute_dtype=None):
                          momentum=0.1 if bn.momentum is None else bn.momentum, eps=bn.eps, layer_id=ly["layer_id"],
                          num_batches_tracked=bn.num_batches_tracked if (training and bn.track_running_stats) else None))
         tensors += [conv.weight, conv.bias, bn.weight, bn.bias, bn.running_mean, bn.running_var]
-    return _ConvStackFn.apply(x, bool(training), rng or RngState(), T, tuple(meta), *tensors)
+    return _ConvStackFn.apply(x, bool(training), rng or RngState(), T, tuple(meta), bn_sync, *tensors)

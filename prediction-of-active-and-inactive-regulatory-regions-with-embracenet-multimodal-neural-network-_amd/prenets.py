@@ -43,7 +43,7 @@ class FFNN_pre(nn.Module):
         self.use_hip = True
 
     def forward(self, x, rng=None):
-        if not (self.use_hip and x.is_cuda):
+        if not self.use_hip:                                 # explicit A/B switch only; CPU tensors raise in the HIP path
             return self.model(x)
         T = self.compute_dtype or self.model[0].weight.dtype
         mods = list(self.model)
@@ -72,9 +72,13 @@ class CNN_pre(nn.Module):
         self.CNN_model = nn.Sequential(*stack)
         self.compute_dtype = None
         self.use_hip = True
+        # data parallelism: False = every rank normalises with the statistics of its own rows (throughput default, what
+        # torch DDP does); True = BatchNorm statistics of the GLOBAL batch, i.e. the single-process result of the
+        # reference (CNN_pre.py:41), at one small all-reduce per block and direction.
+        self.sync_batchnorm = False
 
     def forward(self, x, rng=None):
-        if not (self.use_hip and x.is_cuda):
+        if not self.use_hip:                                 # explicit A/B switch only; CPU tensors raise in the HIP path
             y = self.CNN_model(x)
             return y.reshape(y.size(0), -1)
         mods = list(self.CNN_model)
@@ -83,4 +87,8 @@ class CNN_pre(nn.Module):
             conv, bn, drop = mods[i], mods[i + 1], mods[i + 4]
             layers.append(dict(conv=conv, bn=bn, drop_p=float(drop.p), layer_id=_CNN_LAYER_ID0 + i // 5))
         T = self.compute_dtype or mods[0].weight.dtype
-        return F_.conv_stack(x, layers, self.training, rng=rng, compute_dtype=T)
+        bn_sync = None
+        if getattr(self, "sync_batchnorm", False) and self.training:   # (attribute absent in older pickles)
+            from . import dist as D
+            bn_sync = D.allreduce_sum_ if D.collectives_on() else None
+        return F_.conv_stack(x, layers, self.training, rng=rng, compute_dtype=T, bn_sync=bn_sync)

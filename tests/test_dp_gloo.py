@@ -27,6 +27,11 @@ def _problem():
     return B, c, X, W, b, Wp, bp, y
 
 
+def _bn_activations():
+    from oracle import datagen as dg
+    return dg.uniform("dp/bn", (48, 20, 6), -1.0, 2.0)          # [B][L][C] channels-last, as the conv block stores it
+
+
 def _shard_grads(rows, pos_n, seed, step):
     """oracle forward/backward of rows [r0, r0+n) with GLOBAL (pos, n) class counts; returns loss numerator share
     and parameter gradients."""
@@ -78,6 +83,13 @@ def _worker(rank, world, port, out):
     if rank == 0:
         np.savez(out, loss=total.numpy(), counts=counts.numpy(), **{f"g{i}": p.grad.numpy() for i, p in enumerate(params)})
     np.save(out + f".idx{rank}.npy", idx)
+    # BatchNorm statistics of the global batch (8e(2)): the exchanged vector is {sum, sum of squares, rows} per channel,
+    # the layout emb_convblock_fwd(bn_phase=1) writes; the all-reduced vector must give the full batch's mean / variance
+    act = _bn_activations()[rows[0]:rows[0] + rows[1]]
+    sums = torch.from_numpy(np.concatenate([act.sum((0, 1)), (act ** 2).sum((0, 1)), [act.shape[0] * act.shape[1]]]))
+    dist.allreduce_sum_(sums)
+    if rank == 0:
+        np.save(out + ".bn.npy", sums.numpy())
     dist.barrier()
     tdist.destroy_process_group()
 
@@ -96,3 +108,23 @@ def test_two_rank_step_equals_single_process(tmp_path):
         assert np.abs(got[f"g{i}"] - g).max() < 1e-12, i
     halves = np.concatenate([np.load(out + f".idx{r}.npy") for r in range(2)])
     assert np.array_equal(halves, idx), "selection indices depend on the sharding"
+    act, bn = _bn_activations(), np.load(out + ".bn.npy")
+    C, n = act.shape[2], bn[-1]
+    assert n == act.shape[0] * act.shape[1]
+    mean, var = bn[:C] / n, bn[C:2 * C] / n - (bn[:C] / n) ** 2
+    assert np.abs(mean - act.mean((0, 1))).max() < 1e-12 and np.abs(var - act.var((0, 1))).max() < 1e-12
+
+
+def test_sync_batchnorm_switch_reaches_the_sequence_prenetwork():
+    sys.path.insert(0, ROOT)
+    import embracenet_amd as ea
+    from embracenet_amd import dist
+    from oracle.configs import CONFIGS, FixedTrial
+    hp, F_in = CONFIGS["small"]
+    model = ea.EmbraceNetMultimodal(FixedTrial(hp), cell_line="A549", task="active_E_vs_inactive_E", device="cpu",
+                                    in_features_FFNN=F_in)
+    assert model.CNN.sync_batchnorm is False                     # throughput default: local statistics
+    assert dist.set_sync_batchnorm(model) == 1 and model.CNN.sync_batchnorm is True
+    assert dist.set_sync_batchnorm(model, False) == 1 and model.CNN.sync_batchnorm is False
+    t = torch.ones(3, dtype=torch.float64)
+    assert dist.allreduce_sum_(t) is t and t.tolist() == [1, 1, 1]   # single process: identity

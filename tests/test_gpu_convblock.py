@@ -206,3 +206,64 @@ def test_base_code_input_equals_onehot_input(ea, spec):
     assert torch.equal(o1, o2)
     for a, b in zip(g1, g2):
         assert torch.equal(a, b)
+
+
+@pytest.mark.parametrize("dt", ["f64", "bf16"])
+@pytest.mark.parametrize("name,B,split,spec", [("a549", 24, 16, [(4, 64, 15), (64, 32, 15)]),
+                                                ("deep", 10, 3, [(4, 32, 5), (32, 32, 5), (32, 128, 11)])])
+def test_global_batch_batchnorm_over_two_shards_equals_one_process(ea, name, B, split, spec, dt):
+    """with bn_sync the sharded stack reproduces the single-process stack -- outputs, BatchNorm running
+    statistics, and parameter gradients summed over the shards.  Two 'ranks' run one after the other on the one GPU; the
+    all-reduce callable is emulated by fixed-point passes: pass p replays the global sums of exchange points < p (known
+    from the pass before) and records the local sums of point p, so after 2*n_layers+1 passes every exchange used the
+    true global value -- exactly what an all-reduce delivers.  Dropout is on: its mask is keyed on the global row."""
+    F = ea.functional
+    T = TD[dt]
+    P = torch.float64 if dt == "f64" else torch.float32
+    x = torch.from_numpy(dg.onehot_sequence(f"sbn/{name}/x", B)).to(DEV, P)
+    def blocks():
+        bl = [Blk(f"sbn/{name}/{i}", ci, co, k, P) for i, (ci, co, k) in enumerate(spec)]
+        for b in bl:
+            b.conv.to(DEV); b.bn.to(DEV)
+        return bl, [dict(conv=b.conv, bn=b.bn, drop_p=0.3 if i == 0 else 0.0, layer_id=4 + i) for i, b in enumerate(bl)]
+    full, layers = blocks()
+    out_full = F.conv_stack(x, layers, True, rng=F.RngState(7, 3, None, 0), compute_dtype=T)
+    dout = torch.from_numpy(dg.uniform(f"sbn/{name}/dout", tuple(out_full.shape), -1, 1)).to(DEV, T)
+    out_full.backward(dout)
+
+    shards = [(0, split), (split, B - split)]
+    n_sync = 2 * len(spec)
+    known = []                                                 # global sums of exchange points 0 .. p-1
+    for p in range(n_sync + 1):
+        local, outs, ranks = [], [], []
+        for r, (row0, rows) in enumerate(shards):
+            bl, ly = blocks()
+            seen = []
+            def sync(t, seen=seen):
+                i = len(seen)
+                seen.append(t.clone())
+                if i < len(known):
+                    t.copy_(known[i])
+                return t
+            o = F.conv_stack(x[row0:row0 + rows], ly, True, rng=F.RngState(7, 3, None, row0), compute_dtype=T, bn_sync=sync)
+            o.backward(dout[row0:row0 + rows])
+            assert len(seen) == n_sync
+            local.append(seen); outs.append(o); ranks.append(bl)
+        if p < n_sync:
+            known.append(local[0][p] + local[1][p])
+    assert float(known[0][-1]) == B * 256                      # the row count rides along in the exchanged vector
+
+    tol = 1e-9 if dt == "f64" else 3e-2
+    got = torch.cat(outs).double()
+    assert (got - out_full.double()).abs().max().item() <= tol * max(1.0, out_full.double().abs().max().item())
+    for i, fb in enumerate(full):
+        for j, nm in enumerate(("w", "b", "gamma", "beta")):
+            ref = fb.params()[j].grad.double()
+            summed = ranks[0][i].params()[j].grad.double() + ranks[1][i].params()[j].grad.double()
+            if nm == "b":
+                continue                                       # mathematically zero behind BatchNorm
+            assert (summed - ref).abs().max().item() <= tol * 20 * max(1e-3, ref.abs().max().item()), (i, nm)
+        for rk in ranks:                                       # every rank tracks the global statistics
+            assert (rk[i].bn.running_mean.double() - fb.bn.running_mean.double()).abs().max() < max(tol, 1e-6)
+            assert (rk[i].bn.running_var.double() - fb.bn.running_var.double()).abs().max() < max(tol, 1e-6)
+            assert int(rk[i].bn.num_batches_tracked) == 1
