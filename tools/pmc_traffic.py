@@ -1,0 +1,57 @@
+#!/usr/bin/env python3
+"""Developer tool: HBM traffic per launch of the two fusion kernels from rocprofv3 PMC passes -> profiles/pmc_traffic.json
+(the file bench.py reads for `roofline.traffic`).
+
+Collect on the GPU box, one counter per pass (FETCH_SIZE and WRITE_SIZE do not fit one pass, MI355X_MICROARCH.md):
+    cd /tmp && export TMPDIR=/tmp      # rocprofv3 scratch
+    rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $GRAFT_REPO_ROOT/gpurun_out/pmc_fetch -- python3 bench.py --roofline-only
+    rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $GRAFT_REPO_ROOT/gpurun_out/pmc_write -- python3 bench.py --roofline-only
+then here:  python tools/pmc_traffic.py gpurun_out/pmc_fetch gpurun_out/pmc_write [workload]
+
+Corrections as the guide prescribes for gfx950: counters are in KiB; FETCH_SIZE tallies 128-byte requests at 64 bytes,
+so it is doubled.  bytes per C-ABI call = (2*FETCH + WRITE) * 1024, summed over the kernels one call launches
+(emb_embrace_bwd = backward kernel + slab reduction)."""
+import csv, glob, json, os, sys
+from collections import defaultdict
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+GROUPS = {"embrace_fwd_kernel": ("embrace_fwd",), "embrace_bwd_kernel": ("embrace_bwd_kernel", "multi_reduce_kernel")}
+
+
+def mean_counter(directory, counter):
+    acc = defaultdict(lambda: defaultdict(float))              # kernel -> dispatch -> value summed over its rows
+    for path in glob.glob(os.path.join(directory, "**", "*counter_collection.csv"), recursive=True):
+        for row in csv.DictReader(open(path)):
+            if row["Counter_Name"] == counter:
+                acc[row["Kernel_Name"]][row["Dispatch_Id"]] += float(row["Counter_Value"])
+    return {k: sum(v.values()) / len(v) for k, v in acc.items()}
+
+
+def main():
+    fetch_dir, write_dir = sys.argv[1], sys.argv[2]
+    workload = sys.argv[3] if len(sys.argv) > 3 else "cfg2"
+    fetch, write = mean_counter(fetch_dir, "FETCH_SIZE"), mean_counter(write_dir, "WRITE_SIZE")
+    out, raw = {}, {}
+    for group, needles in GROUPS.items():
+        total = 0.0
+        for needle in needles:
+            names = [k for k in fetch if needle in k]
+            if not names:
+                raise SystemExit(f"no kernel matching {needle!r} in {fetch_dir}")
+            for name in names:
+                f, w = fetch[name], write.get(name, 0.0)
+                raw[needle] = {"FETCH_SIZE": f, "WRITE_SIZE": w}
+                total += (2.0 * f + w) * 1024.0
+        out[group] = int(round(total))
+    path = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+    doc = json.load(open(path)) if os.path.exists(path) else {}
+    doc[workload] = out
+    doc["_note"] = ("bytes per C-ABI call = (2*FETCH_SIZE + WRITE_SIZE)*1024, FETCH_SIZE doubled per MI355X_MICROARCH.md (gfx950 "
+                    "tallies 128-B requests at 64 B); embrace_bwd = backward kernel + slab reduction kernel; tools/pmc_traffic.py")
+    doc["_raw_KiB"] = raw
+    json.dump(doc, open(path, "w"), indent=1)
+    print(json.dumps(doc, indent=1))
+
+
+if __name__ == "__main__":
+    main()
