@@ -232,7 +232,7 @@ template <typename T, int MT, bool WREG> static size_t conv_t_lds(int cin, int K
 
 
 template <typename T, int BN, bool FWD>
-__global__ __launch_bounds__(kThreads) void conv_direct_kernel(const T* __restrict__ x, const T* __restrict__ w,
+__global__ __launch_bounds__(kThreads, 2) void conv_direct_kernel(const T* __restrict__ x, const T* __restrict__ w,
                                                                const typename AccOf<T>::type* __restrict__ bias, T* __restrict__ out,
                                                                typename AccOf<T>::type* __restrict__ partial, int B, int L, int cin,
                                                                int KK, int N, int pad, int SB, int tiles_t, int slot, int tiles_n) {
@@ -481,7 +481,7 @@ int launch_conv_direct(int dtype, bool fwd, const void* x, const void* w, const 
 // ------------------------------------------------------------------------------------ weight gradient
 // slab[slice][o][n] += sum over the slice's row tiles of dy[r][o] * xview[r][n]  (n = tap*cin + ci);  column KK = sum dy
 template <typename T, int BMW>
-__global__ __launch_bounds__(kThreads) void conv_wgrad_direct_kernel(const T* __restrict__ dy, const T* __restrict__ x,
+__global__ __launch_bounds__(kThreads, 2) void conv_wgrad_direct_kernel(const T* __restrict__ dy, const T* __restrict__ x,
                                                                      typename AccOf<T>::type* __restrict__ slab, int B, int L, int cin,
                                                                      int KK, int Cout, int pad, int SB, int tiles_t, int slot,
                                                                      int tiles_m, int n_tiles, int m_tiles, int S) {

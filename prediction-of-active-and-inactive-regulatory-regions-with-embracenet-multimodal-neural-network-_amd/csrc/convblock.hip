@@ -43,7 +43,7 @@ constexpr int kPoolK = 10, kPoolS = 2;   // CNN_pre.py:17,19
 // ------------------------------------------------------------------------------------ conv GEMM
 // FWD: C = view(x).wpack^T + bias, per-tile column sums of C and C^2 -> partial[tm][2][N].   !FWD: plain store.
 template <class Cfg, bool FWD>
-__global__ __launch_bounds__(kThreads) void conv_gemm_kernel(const typename Cfg::T* __restrict__ x,
+__global__ __launch_bounds__(kThreads, 2) void conv_gemm_kernel(const typename Cfg::T* __restrict__ x,
                                                              const typename Cfg::T* __restrict__ w,
                                                              const typename Cfg::M::Acc* __restrict__ bias,
                                                              typename Cfg::T* __restrict__ out,
@@ -481,7 +481,7 @@ __global__ __launch_bounds__(256) void bn_bwd_affine_kernel(const T* __restrict_
 // ------------------------------------------------------------------------------------- wgrad
 // slab[s][Cout][KK+1] = dy^T . [view(x) | 1] over rows [s*kper, (s+1)*kper)
 template <class Cfg>
-__global__ __launch_bounds__(kThreads) void conv_wgrad_kernel(const typename Cfg::T* __restrict__ dy,
+__global__ __launch_bounds__(kThreads, 2) void conv_wgrad_kernel(const typename Cfg::T* __restrict__ dy,
                                                               const typename Cfg::T* __restrict__ x,
                                                               typename Cfg::M::Acc* __restrict__ slab, int R, int L, int cin,
                                                               int KK, int Cout, int pad, int kper, int tiles_n, int tiles_per_slice,

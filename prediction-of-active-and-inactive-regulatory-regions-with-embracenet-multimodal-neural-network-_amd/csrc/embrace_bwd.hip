@@ -44,8 +44,10 @@ template <typename T, typename OutT> struct BwdJob {
   OutT* slab;          // [S][M][N+1] partial sums when S > 1
 };
 
+// (second launch bound = 2 waves per SIMD: caps the kernel at 256 registers, which makes hipcc keep the MFMA accumulators in
+// VGPRs; with the default 512-register budget it put them in AGPRs and copied all 16 in and out around every MFMA group)
 template <typename T>
-__global__ __launch_bounds__(kThreads) void embrace_bwd_kernel(const T* __restrict__ dE, const uint8_t* __restrict__ code,
+__global__ __launch_bounds__(kThreads, 2) void embrace_bwd_kernel(const T* __restrict__ dE, const uint8_t* __restrict__ code,
                                                                int c, int vec_e,
                                                                const BwdJob<T, T> dg1,
                                                                const BwdJob<T, typename AccOf<T>::type> wg1,

@@ -12,7 +12,7 @@
 namespace emb {
 
 template <class Cfg>
-__global__ __launch_bounds__(kThreads) void embrace_fwd_kernel(
+__global__ __launch_bounds__(kThreads, 2) void embrace_fwd_kernel(
     const typename Cfg::T* __restrict__ X0, const typename Cfg::T* __restrict__ X1,
     const typename Cfg::T* __restrict__ W0, const typename Cfg::T* __restrict__ W1,
     const typename Cfg::M::Acc* __restrict__ b0, const typename Cfg::M::Acc* __restrict__ b1,

@@ -201,10 +201,13 @@ template <int S> struct FragRead<__bf16, true, S> {
   // image [k][row]: two transposing reads, each a 4(k) x 16(row) block per 16-lane group
   __device__ static bf16x8 get(const __bf16* tile, int row_base, int k_base, int lane) {
     const int g = lane >> 4, w = lane & 15, q = w >> 2, p = w & 3;
-    const __bf16* a0 = tile + (k_base + 8 * g + q) * S + row_base + 4 * p;
+    // `tile` reaches here as a generic pointer (selected from the double-buffer table at run time), and a generic ->
+    // LDS pointer cast costs a 64-bit add, a null compare and a select per read.  The low 32 bits of a generic LDS
+    // address ARE the LDS offset (the aperture base lives in the high half), so form the 32-bit address directly.
+    const uint32_t a0 = (uint32_t)(uintptr_t)tile + 2u * (uint32_t)((k_base + 8 * g + q) * S + row_base + 4 * p);
     typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
     const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(a0));
-    const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(a0 + 4 * S));
+    const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(a0 + 2u * 4u * S));
     union { struct { s16x4 lo, hi; } s; bf16x8 v; } u;
     u.s.lo = lo;
     u.s.hi = hi;

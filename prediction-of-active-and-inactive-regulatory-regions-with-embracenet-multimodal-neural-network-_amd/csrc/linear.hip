@@ -29,7 +29,7 @@ template <> struct LinCfg<__bf16> {
 };
 
 template <class Cfg>
-__global__ __launch_bounds__(kThreads) void linear_fwd_kernel(GemmOperand<typename Cfg::T> X, GemmOperand<typename Cfg::T> W,
+__global__ __launch_bounds__(kThreads, 2) void linear_fwd_kernel(GemmOperand<typename Cfg::T> X, GemmOperand<typename Cfg::T> W,
                                                               EpiLinear<typename Cfg::T, typename Cfg::M::Acc> epi,
                                                               const uint64_t* step_dev, uint64_t step_val, int layer_id,
                                                               int B, int K, int N, int tiles_n, int ntiles) {
@@ -77,7 +77,7 @@ template <typename T> struct LinBwdArgs {
   bool vec_dx, vec_dw;
 };
 
-template <typename T> __global__ __launch_bounds__(kThreads) void linear_bwd_kernel(const LinBwdArgs<T> a) {
+template <typename T> __global__ __launch_bounds__(kThreads, 2) void linear_bwd_kernel(const LinBwdArgs<T> a) {
   using P = typename AccOf<T>::type;
   extern __shared__ __attribute__((aligned(16))) char arena[];
   const int bid = blockIdx.x;
