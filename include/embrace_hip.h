@@ -241,6 +241,21 @@ int emb_convblock_needs_y(int B, int L, int cin_pad, int Cout, int k, int dtype)
 int emb_reduce_defer(int on);
 int emb_reduce_flush(emb_stream_t stream);
 
+/* ---- input staging ---------------------------------------------------------------------------
+ * The split (features, sequence codes / one-hot windows, labels) stays resident in HBM; a batch is a row gather:
+ *   dst[t][i][0..row_bytes[t]) = src[t][idx[i]][0..row_bytes[t])     t < n_tables (1..4), i < n
+ * for all tables in one launch (they share the index list idx[n], int64 on the device; n_rows = rows of every source
+ * table).  src / dst / row_bytes are HOST arrays of n_tables entries (device pointers and sizes in bytes).  Replaces the
+ * per-sample fetch + .to(device) of Dataset_Wrap.__getitem__ and the DataLoader collate (data_pipe/dataprepare.py:399-412,
+ * :589-594).  An index outside [0, n_rows) yields a zero row (never an out-of-bounds read). */
+int emb_gather_rows(const void* const* src, void* const* dst, const int64_t* row_bytes, int n_tables, const int64_t* idx,
+                    int64_t n, int64_t n_rows, emb_stream_t stream);
+/* HOST helper for the balanced batch lists (BalancePos_BatchSampler.__iter__, data_pipe/dataprepare.py:431-447, shuffles
+ * with Python's `random`): random.shuffle(items) restated natively -- MT19937 state[624] + position as returned by
+ * random.Random(seed).getstate(), advanced in place, so consecutive shuffles continue one stream exactly as the module
+ * generator does.  items[n] int64 in host memory, n < 2^31.  No device work. */
+int emb_mt19937_shuffle(uint32_t* state, int* pos, int64_t* items, int64_t n);
+
 /* helpers: dtype conversion (fp32/fp64 master -> bf16 shadow etc.) and a device step counter */
 int emb_cast(const void* src, int src_dtype, void* dst, int dst_dtype, int64_t n, emb_stream_t stream);
 int emb_counter_add(uint64_t* counter, uint64_t inc, emb_stream_t stream);

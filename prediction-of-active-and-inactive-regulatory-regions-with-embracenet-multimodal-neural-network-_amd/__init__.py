@@ -4,7 +4,7 @@ The directory name is fixed by the build contract and is not a Python identifier
 ``embracenet_amd`` (the one-file alias at the repository root) or through importlib.
 Public surface mirrors the reference's BIOINF_tesi.models / BIOINF_tesi.models.utils for this path.
 """
-from . import _lib, dist, functional, inference, metrics, optim, training  # noqa: F401
+from . import _lib, data, dist, functional, inference, metrics, optim, training  # noqa: F401
 from .embracenet import EmbraceNet, EmbraceNetMultimodal  # noqa: F401
 from .inference import EmbraceNetMultimodal_NoTrain  # noqa: F401
 from .metrics import (AUPRC, EarlyStopping, F1_precision_recall, accuracy, get_input_size,  # noqa: F401

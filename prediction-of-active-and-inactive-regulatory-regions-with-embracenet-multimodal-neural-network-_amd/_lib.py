@@ -53,6 +53,8 @@ SIGNATURES = {
     "emb_convblock_bwd": [_vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _f, _i] + [_vp] * 7 + [_i64, _i, _i, _vp, _i, _i, _i, _i, _i, _i, _i, _vp],
     "emb_conv_pack_register": [_vp, _vp, _vp, _i, _i, _i, _i],
     "emb_conv_pack_unregister": [_vp],
+    "emb_gather_rows": [_vp, _vp, _vp, _i, _vp, _i64, _i64, _vp],
+    "emb_mt19937_shuffle": [_vp, _vp, _vp, _i64],
     "emb_reduce_defer": [_i],
     "emb_reduce_flush": [_vp],
     "emb_convblock_needs_y": [_i, _i, _i, _i, _i, _i],

@@ -547,7 +547,6 @@ template <typename T> static ConvWs conv_workspace(int B, int L, int cin_pad, in
   using P = typename AccOf<T>::type;
   using CF = typename ConvCfg<T>::F64;
   using CW = typename ConvCfg<T>::W;
-  constexpr int VEC = Elem<T>::VEC;
   ConvWs w;
   const long R = (long)B * L;
   const int KK = k * cin_pad;

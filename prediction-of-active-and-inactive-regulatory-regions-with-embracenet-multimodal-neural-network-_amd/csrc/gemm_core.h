@@ -206,8 +206,8 @@ template <int S> struct FragRead<__bf16, true, S> {
     // address ARE the LDS offset (the aperture base lives in the high half), so form the 32-bit address directly.
     const uint32_t a0 = (uint32_t)(uintptr_t)tile + 2u * (uint32_t)((k_base + 8 * g + q) * S + row_base + 4 * p);
     typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
-    const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(a0));
-    const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(a0 + 2u * 4u * S));
+    const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(uintptr_t)(a0));
+    const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(uintptr_t)(a0 + 2u * 4u * S));
     union { struct { s16x4 lo, hi; } s; bf16x8 v; } u;
     u.s.lo = lo;
     u.s.hi = hi;

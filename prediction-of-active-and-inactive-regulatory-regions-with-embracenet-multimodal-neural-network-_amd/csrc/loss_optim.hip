@@ -107,7 +107,7 @@ __global__ void adam_kernel(P* __restrict__ p, const P* __restrict__ g, P* __res
   const double step = (double)(step_val + (step_dev ? *step_dev : 0));
   const double bc1 = 1.0 - pow(b1, step), bc2 = 1.0 - pow(b2, step);
   const P step_size = (P)(lr / bc1), bc2s = (P)sqrt(bc2);
-  const P pb1 = (P)b1, pb2 = (P)b2, pwd = (P)wd, peps = (P)eps, omb1 = (P)(1.0 - b1), omb2 = (P)(1.0 - b2);
+  const P pb2 = (P)b2, pwd = (P)wd, peps = (P)eps, omb1 = (P)(1.0 - b1), omb2 = (P)(1.0 - b2);
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
     P pi = p[i];
     const P gi = g[i] + pwd * pi;                 // coupled L2 (torch.optim.Adam weight_decay)

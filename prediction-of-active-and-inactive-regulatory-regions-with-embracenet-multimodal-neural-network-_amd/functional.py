@@ -584,6 +584,48 @@ class _ConvStackFn(torch.autograd.Function):
         return (None, None, None, None, None, None, *grads)
 
 
+class RowGather:
+    """Batch staging: out[t][i] = tables[t][idx[i]] for up to four device tables sharing one int64 device
+    index vector, in ONE launch (csrc/gather.hip).  Tables are [N, ...] contiguous tensors with the same N; they are
+    validated once here, a call only allocates the outputs and launches."""
+
+    def __init__(self, tables):
+        import ctypes
+        tables = tuple(tables)
+        if not 1 <= len(tables) <= 4:
+            raise ValueError("gather_rows: 1 to 4 tables per call")
+        _lib.require_cuda(*tables)
+        self.n_rows = tables[0].shape[0]
+        for t in tables:
+            if t.dim() < 1 or t.shape[0] != self.n_rows or not t.is_contiguous() or t.device != tables[0].device:
+                raise ValueError("gather_rows: tables must be contiguous, on one device, with the same number of rows")
+        if self.n_rows == 0:
+            raise ValueError("gather_rows: empty tables")
+        self.tables, k = tables, len(tables)
+        self._src = (ctypes.c_void_p * k)(*[t.data_ptr() for t in tables])
+        self._rb = (ctypes.c_int64 * k)(*[(t.numel() // self.n_rows) * t.element_size() for t in tables])
+        self._dst = (ctypes.c_void_p * k)()
+        self._meta = [(tuple(t.shape[1:]), t.dtype) for t in tables]
+        self._fn, self._dev = _lib.lib().emb_gather_rows, tables[0].device
+
+    def __call__(self, idx):
+        if idx.dtype != torch.int64 or idx.dim() != 1 or not idx.is_contiguous() or idx.device != self._dev:
+            raise TypeError("gather_rows: idx must be a contiguous 1-D int64 tensor on the tables' device")
+        n = idx.shape[0]
+        outs = [torch.empty((n,) + shape, dtype=dt, device=self._dev) for shape, dt in self._meta]
+        if n:
+            for i, o in enumerate(outs):
+                self._dst[i] = o.data_ptr()
+            check(self._fn(self._src, self._dst, self._rb, len(outs), idx.data_ptr(), n, self.n_rows, stream()), "emb_gather_rows")
+        return outs
+
+
+def gather_rows(tables, idx):
+    """One-shot form of RowGather."""
+    _lib.require_cuda(idx)
+    return RowGather(tables)(idx)
+
+
 def pack_onehot(x):
     """[N, 4, L] one-hot windows (the loader's format, dataprepare.py:398-412) -> [N, L] uint8 base codes: the hot channel,
     4 for an all-zero column.  Done once per data set (host or device); batches then travel and are staged as one byte per

@@ -110,6 +110,8 @@ def weight_reset(x):
 
 
 def get_input_size(data_loader):
+    if hasattr(data_loader, "input_size"):                     # data.device_loaders: no epoch is consumed to find out
+        return data_loader.input_size
     for d, _ in data_loader:
         return d.shape[1]
 

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Generate the golden fixtures G1-G10 by importing the reference on CPU.
+"""Generate the golden fixtures G1-G11 by importing the reference on CPU.
 
 Runs ONLY in the build container (needs /root/reference).  The fixtures it writes under
 tests/golden/ are data (inputs are regenerated from oracle/datagen.py by name; outputs are
@@ -514,7 +514,39 @@ def g10():
     save("G10_inference_twin", arrays, meta)
 
 
+def g11():
+    """Balanced batch index lists: the reference's BalancePos_BatchSampler (dataprepare.py:417-453) over
+    label vectors from oracle/datagen.py, three epochs each (the sampler keeps its lists shuffled between epochs).  The
+    sampler only reads pos_index / neg_index / len() of its data set, so a bare stand-in carries the labels (the
+    reference's Dataset_Wrap needs a scikit-learn older than the one installed here)."""
+    from BIOINF_tesi.data_pipe.dataprepare import BalancePos_BatchSampler
+
+    class Labels:
+        def __init__(self, y):
+            self.pos_index = np.flatnonzero(y == 1).tolist()
+            self.neg_index = np.flatnonzero(y == 0).tolist()
+            self.n = len(y)
+
+        def __len__(self):
+            return self.n
+
+    arrays, meta = {}, {"cases": []}
+    for i, (n, rate, bs, seed) in enumerate([(23, 0.25, 5, 123), (1000, 0.1, 64, 123), (640, 0.3, 64, 7), (37, 0.5, 100, 123),
+                                             (300, 0.02, 32, 123), (12, 0.0, 4, 123)]):
+        y = dg.labels(f"g11/{i}/y", n, rate).reshape(-1) if rate > 0 else np.zeros(n, dtype=np.int64)
+        sampler = BalancePos_BatchSampler(Labels(y), bs, random_state=seed)
+        sizes, flat = [], []
+        for _ in range(3):
+            batches = list(iter(sampler))
+            sizes.append([len(b) for b in batches])
+            flat += [int(v) for b in batches for v in b]
+        arrays[f"c{i}_idx"] = np.asarray(flat, dtype=np.int64)
+        meta["cases"].append(dict(n=n, rate=rate, batch_size=bs, seed=seed, len=len(sampler), sizes=sizes,
+                                  positives=int(y.sum())))
+    save("G11_balanced_batches", arrays, meta)
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g5", "g6", "g7", "g8", "g9", "g10"]
+    which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g5", "g6", "g7", "g8", "g9", "g10", "g11"]
     for w in which:
         globals()[w]()

@@ -123,3 +123,55 @@ def test_inference_twin_helpers_follow_the_reference():
     assert ea.inference.output_size_from_model_params(single["CNN"]) == 58 * hp["CNN_out_channels_l1"] == 1856
     assert ea.inference.checkpoint_name("A549", "t", 3) == "A549_EmbraceNetMultimodal_t_3_test_.pt"
     assert ea.inference.checkpoint_name("A549", "t", 3, augmentation=True) == "A549_EmbraceNetMultimodal_augmentation_t_3_test_.pt"
+
+
+@pytest.mark.parametrize("native", [True, False], ids=["native-shuffle", "python-shuffle"])
+def test_g11_balanced_batches_match_the_reference_sampler(native):
+    """Row f4: data.BalancedBatchSampler yields the index lists of the reference's BalancePos_BatchSampler (fixture G11,
+    three epochs per case: the in-place shuffles carry over from epoch to epoch), bit for bit."""
+    from embracenet_amd import data
+    from oracle import datagen as dg
+    g = Golden("G11_balanced_batches")
+    for i, case in enumerate(g.meta["cases"]):
+        n, rate = case["n"], case["rate"]
+        y = dg.labels(f"g11/{i}/y", n, rate).reshape(-1) if rate > 0 else np.zeros(n, dtype=np.int64)
+        assert int(y.sum()) == case["positives"]
+        s = data.BalancedBatchSampler(y, case["batch_size"], random_state=case["seed"], native=native)
+        assert len(s) == case["len"]
+        flat, sizes = [], []
+        for _ in range(3):
+            batches = list(iter(s))
+            sizes.append([len(b) for b in batches])
+            flat += [v for b in batches for v in b]
+        assert sizes == case["sizes"], i
+        assert np.array_equal(np.asarray(flat, dtype=np.int64), g[f"c{i}_idx"]), i
+        assert len(sizes[0]) == case["len"] + 1                  # the reference yields one batch more than len()
+        assert sorted(flat[:n]) == list(range(n))                # every row exactly once per epoch
+
+
+@pytest.mark.parametrize("n,bs,seed", [(23, 10, 153), (200, 64, 153), (64, 64, 7), (5, 8, 1)])
+def test_shuffled_batches_match_a_torch_dataloader(n, bs, seed):
+    """The reference's test loader is DataLoader(..., batch_size*2, shuffle=True, generator=manual_seed(random_state+30))
+    (dataprepare.py:592-594): data.ShuffledBatchSampler must walk through the same index batches, epoch after epoch."""
+    from embracenet_amd import data
+    ref = torch.utils.data.DataLoader(torch.arange(n), batch_size=bs, shuffle=True,
+                                      generator=torch.Generator("cpu").manual_seed(seed))
+    mine = data.ShuffledBatchSampler(n, bs, random_state=seed)
+    assert len(mine) == len(ref)
+    for _ in range(3):
+        assert [b.tolist() for b in ref] == list(iter(mine))
+
+
+def test_native_shuffle_equals_python_random_on_long_lists():
+    """emb_mt19937_shuffle vs random.Random(seed).shuffle on lists long enough to regenerate the twister state many times
+    and to exercise the rejection loop of _randbelow, with consecutive shuffles continuing one stream."""
+    import random
+    from embracenet_amd import data
+    for seed, sizes in ((123, (50001, 1, 0, 4097, 2)), (2 ** 40 + 5, (1000, 65536))):
+        rng, sh = random.Random(seed), data._PyShuffler(seed, native=True)
+        for n in sizes:
+            want = list(range(n))
+            rng.shuffle(want)
+            got = np.arange(n, dtype=np.int64)
+            sh.shuffle(got)
+            assert got.tolist() == want, (seed, n)
