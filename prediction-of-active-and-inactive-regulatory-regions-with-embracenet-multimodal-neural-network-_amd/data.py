@@ -160,6 +160,7 @@ class _Epochs:
         self._made, self._next = {}, 0                           # epoch -> (flat device indices, [(offset, size)])
         self._gather = F_.RowGather((split.x1, split.seq, split.y))
         self._last = (None, None)                                # ((epoch, batch), gathered tensors)
+        self._staging = {}                                       # batch size -> (x1, seq, y, y[:, None]) reused every batch
 
     def batch(self, e, i):
         """(x1, seq, y[:, None]) of batch i of epoch e: ONE gather launch serves both modality views (whichever asks first
@@ -167,8 +168,15 @@ class _Epochs:
         if self._last[0] != (e, i):
             idx, spans = self.get(e)
             at, size = spans[i]
-            x1, seq, y = self._gather(idx[at:at + size])
-            self._last = ((e, i), (x1, seq, y.view(-1, 1)))
+            bufs = self._staging.get(size)
+            if bufs is None:                                     # one set of staging buffers per batch size: like a DataLoader
+                x1, seq, y = self._gather(idx[at:at + size])     # with pinned buffers, a batch is valid until the next one;
+                bufs = self._staging[size] = (x1, seq, y, y.view(-1, 1))
+                for t in bufs:                                   # training.StepRunner may capture these addresses in its
+                    t._emb_staging = True                        # step graphs instead of copying every batch
+            else:
+                self._gather(idx[at:at + size], out=bufs[:3])
+            self._last = ((e, i), (bufs[0], bufs[1], bufs[3]))
         return self._last[1]
 
     def get(self, e):

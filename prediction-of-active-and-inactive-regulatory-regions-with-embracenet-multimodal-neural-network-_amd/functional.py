@@ -608,11 +608,14 @@ class RowGather:
         self._meta = [(tuple(t.shape[1:]), t.dtype) for t in tables]
         self._fn, self._dev = _lib.lib().emb_gather_rows, tables[0].device
 
-    def __call__(self, idx):
+    def __call__(self, idx, out=None):
+        """`out`: tensors of a previous call with the same number of indices, to be overwritten (staging buffers)."""
         if idx.dtype != torch.int64 or idx.dim() != 1 or not idx.is_contiguous() or idx.device != self._dev:
             raise TypeError("gather_rows: idx must be a contiguous 1-D int64 tensor on the tables' device")
         n = idx.shape[0]
-        outs = [torch.empty((n,) + shape, dtype=dt, device=self._dev) for shape, dt in self._meta]
+        outs = out if out is not None else [torch.empty((n,) + shape, dtype=dt, device=self._dev) for shape, dt in self._meta]
+        if out is not None and (len(outs) != len(self._meta) or any(o.shape[0] != n for o in outs)):
+            raise ValueError("gather_rows: `out` does not fit this call")
         if n:
             for i, o in enumerate(outs):
                 self._dst[i] = o.data_ptr()

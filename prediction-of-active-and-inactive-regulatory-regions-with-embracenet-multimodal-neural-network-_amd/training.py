@@ -143,10 +143,14 @@ class StepRunner:
             ent["seen"] += 1
             if ent["seen"] <= _GRAPH_WARMUP:
                 return None                                 # eager (the caller's normal path)
-            st = ent["static"] = dict(
-                x1=torch.empty(tuple(x_1.shape), dtype=dt, device=dev), x2=torch.empty(tuple(x_2.shape), dtype=dt2, device=dev),
-                y=torch.empty(target.reshape(-1).shape, dtype=torch.int64, device=dev), table=M.StepTable(1, dev))
-            st["x1"].copy_(x_1, non_blocking=True); st["x2"].copy_(x_2, non_blocking=True); st["y"].copy_(target.reshape(-1), non_blocking=True)
+            def static(t, dtype):
+                # data.device_loaders hands out reused staging buffers: capture THEIR addresses (no copy per step);
+                # anything else (host batches, a list of device batches) is copied into a buffer owned by the graph
+                if getattr(t, "_emb_staging", False) and t.dtype == dtype and t.device == torch.device(dev) and t.is_contiguous():
+                    return t
+                return torch.empty(tuple(t.shape), dtype=dtype, device=dev).copy_(t, non_blocking=True)
+            st = ent["static"] = dict(x1=static(x_1, dt), x2=static(x_2, dt2), table=M.StepTable(1, dev))
+            st["y"] = static(target, torch.int64).reshape(-1)
             torch.cuda.synchronize()
             g = torch.cuda.CUDAGraph()
             with torch.cuda.graph(g):
@@ -157,9 +161,9 @@ class StepRunner:
                     st["out"], st["loss"] = self._eval_step_eager(st["x1"], st["x2"], st["y"], st["table"])
             ent["g"] = g                                    # (capture does not execute: replay below runs this batch)
         st = ent["static"]
-        st["x1"].copy_(x_1, non_blocking=True)
-        st["x2"].copy_(x_2, non_blocking=True)
-        st["y"].copy_(target.reshape(-1), non_blocking=True)
+        for buf, t in ((st["x1"], x_1), (st["x2"], x_2), (st["y"], target)):
+            if not (t.is_cuda and t.data_ptr() == buf.data_ptr() and t.dtype == buf.dtype):
+                buf.copy_(t.reshape(buf.shape), non_blocking=True)
         ent["g"].replay()
         loss_slot, count_slot = table.slot()
         loss_slot.copy_(st["table"].loss[:1])

@@ -61,7 +61,7 @@ def test_device_loaders_feed_the_harness_like_host_batches(ea, pack):
     hp, F_in = CONFIGS["small"]
     xtr, str_, ytr = _split("dl/train", 150, F_in, 0.3)
     xte, ste, yte = _split("dl/test", 70, F_in, 0.3)
-    epochs, bs = 3, 32
+    epochs, bs = 4, 32
 
     def host_lists(x1, seq, y, sampler):
         per_epoch = []
@@ -83,7 +83,7 @@ def test_device_loaders_feed_the_harness_like_host_batches(ea, pack):
             self.e += 1
             return iter(self.per_epoch[self.e - 1][self.which])
 
-    def run(device_side):
+    def run(device_side, graph=False):
         model = ea.EmbraceNetMultimodal(FixedTrial(hp), cell_line="A549", task="active_E_vs_inactive_E", device=DEV,
                                         in_features_FFNN=F_in)
         torch.manual_seed(3)
@@ -103,10 +103,11 @@ def test_device_loaders_feed_the_harness_like_host_batches(ea, pack):
             train = {"FFNN": Replay(tr, 0, len(s_tr)), "CNN": Replay(tr, 1, len(s_tr))}
             test = {"FFNN": Replay(te, 0, len(s_te)), "CNN": Replay(te, 1, len(s_te))}
         res = training.fit_multimodal(model, train, test, DEV, "A549", "active_E_vs_inactive_E", optimizer=opt,
-                                      num_epochs=epochs, patience=10, verbose=False, precision="float32")
+                                      num_epochs=epochs, patience=10, verbose=False, precision="float32", graph=graph)
         return res, {k: v.detach().cpu().clone() for k, v in model.state_dict().items()}
 
-    (ra, sa), (rb, sb) = run(False), run(True)
-    assert ra[0] == rb[0] and ra[1] == rb[1]
+    (ra, sa), (rb, sb), (rc, sc) = run(False), run(True), run(True, graph=True)
+    assert ra[0] == rb[0] == rc[0] and ra[1] == rb[1] == rc[1]
     for k in sa:
         assert torch.equal(sa[k], sb[k]), k
+        assert torch.equal(sa[k], sc[k]), (k, "graph-replayed steps on the loader's staging buffers")
