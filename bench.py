@@ -186,6 +186,7 @@ def main():
     ap.add_argument("--roofline-only", action="store_true", help="only time the isolated kernels (used under rocprofv3 --pmc)")
     ap.add_argument("--packed-input", action="store_true",
                     help="stage the DNA windows as uint8 base codes (SURVEY 8 row f4) instead of the loader's [B,4,256] floats")
+    ap.add_argument("--no-fused-loss", action="store_true", help="A/B: head, loss and head backward as three launches")
     ap.add_argument("--sync-bn", action="store_true", help="N>1: BatchNorm statistics of the global batch (parity switch, "
                     "dist.set_sync_batchnorm); default is local statistics")
     ap.add_argument("--split-graph", action="store_true", help="N>1: keep the all-reduce outside the captured graphs")
@@ -239,12 +240,19 @@ def main():
     flat = D.FlatGrads(model.parameters(), extra=2) if dist_path else None
     local_counts = F.count_labels(y).to(torch.float32) if dist_path else None
 
+    fused_loss = (not args.no_fused_loss) and model.fused_loss_ready(B)
+
     def fwd_bwd():
         if flat is None:
             opt.zero_grad(set_to_none=True)
+        if fused_loss:                                    # the head's launch takes the loss and its own backward along
+            model.arm_fused_loss(F.FusedLoss(y, counts, dist_path, loss_slot, conf_slot, ticks))
         out = model([x1, x2], is_training=True)
-        _, dlogits = F.weighted_ce_with_grad(out, y, class_counts=counts, global_counts=dist_path, confusion=conf_slot,
-                                             loss_out=loss_slot, ticks=ticks)
+        if fused_loss:
+            dlogits = out.detach()                        # ignored by the head's node (the armed loss is the graph's root)
+        else:
+            _, dlogits = F.weighted_ce_with_grad(out, y, class_counts=counts, global_counts=dist_path, confusion=conf_slot,
+                                                 loss_out=loss_slot, ticks=ticks)
         F.reduce_defer(True)                              # one reduction launch for all weight-gradient slabs of the backward
         out.backward(dlogits)
         F.reduce_defer(False)
@@ -344,7 +352,7 @@ def main():
             "per_gpu": value / world,
             "config": {"workload": wl["name"], "per_gpu_batch": B, "global_batch": B * world,
                        "parallelism": f"dp{world} (batch-sharded, RCCL all-reduce of gradients)" if world > 1 else "single GPU",
-                       "step": "zero_grad+fwd+weighted CE+bwd" + ("+allreduce" if world > 1 else "") + "+fused Adam",
+                       "loss": "inside the classifier-head launch" if fused_loss else "own launch", "step": "zero_grad+fwd+weighted CE+bwd" + ("+allreduce" if world > 1 else "") + "+fused Adam",
                        "graph": bool(use_graph), "graph_mode": graph_mode,
                        "sequence_input": "uint8 base codes [B,256]" if args.packed_input else "one-hot [B,4,256] (loader format)", "rng": "philox (device-side modality dropout and selection)",
                        "batchnorm": "global-batch statistics (all-reduced sums)" if (args.sync_bn and D.collectives_on()) else "local statistics per rank",

@@ -241,6 +241,24 @@ int emb_convblock_needs_y(int B, int L, int cin_pad, int Cout, int k, int dtype)
 int emb_reduce_defer(int on);
 int emb_reduce_flush(emb_stream_t stream);
 
+/* ---- classifier head + loss in one launch (rows a11-a13 of SURVEY 8 fused) ------------------------------------
+ * emb_head_ce      logits[B][2] T = E[B][K] . W[2][K]^T + bias (the final nn.Linear(width, 2), EmbraceNetMultimodal.py:151-154,
+ *                  :190; W / bias fp32), the per-batch class-weighted cross-entropy on them (semantics of emb_weighted_ce) and,
+ *                  when dE != NULL, the head's backward: dE[B][K] T = dlogits . W, with dW / db left as per-workgroup partial
+ *                  sums in `workspace`.  tick_a / tick_b as in emb_weighted_ce.  T in {f32, bf16}, K % 4 == 0, K <= 1024
+ *                  (emb_head_ce_supported).  Replaces three dependent launches (last emb_mlp_fwd layer, emb_weighted_ce, last
+ *                  emb_mlp_bwd layer).
+ * emb_head_ce_finish  sums the partials (reduce.hip; queued under emb_reduce_defer): dW[2][K], db[2] fp32 (both NULL in
+ *                  evaluation), *loss (fp32) and confusion[4] int64 = {tp, predicted positives, positives, rows} of this call's
+ *                  rows.  `workspace` must stay untouched between the two calls (and until emb_reduce_flush when deferred). */
+int emb_head_ce_supported(int B, int K, int dtype);
+int64_t emb_head_ce_workspace_bytes(int B, int K);
+int emb_head_ce(const void* E, const void* W, const void* bias, const int64_t* target, int64_t* class_counts, int global_counts,
+                void* logits, void* dE, void* workspace, int64_t workspace_bytes, uint64_t* tick_a, uint64_t* tick_b, int B,
+                int K, int dtype, emb_stream_t stream);
+int emb_head_ce_finish(const void* workspace, void* dW, void* db, float* loss, int64_t* confusion, int B, int K,
+                       emb_stream_t stream);
+
 /* ---- input staging ---------------------------------------------------------------------------
  * The split (features, sequence codes / one-hot windows, labels) stays resident in HBM; a batch is a row gather:
  *   dst[t][i][0..row_bytes[t]) = src[t][idx[i]][0..row_bytes[t])     t < n_tables (1..4), i < n

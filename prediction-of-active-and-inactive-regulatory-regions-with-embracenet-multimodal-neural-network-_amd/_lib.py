@@ -53,6 +53,10 @@ SIGNATURES = {
     "emb_convblock_bwd": [_vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _f, _i] + [_vp] * 7 + [_i64, _i, _i, _vp, _i, _i, _i, _i, _i, _i, _i, _vp],
     "emb_conv_pack_register": [_vp, _vp, _vp, _i, _i, _i, _i],
     "emb_conv_pack_unregister": [_vp],
+    "emb_head_ce_supported": [_i, _i, _i],
+    "emb_head_ce_workspace_bytes": [_i, _i],
+    "emb_head_ce": [_vp, _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _i64, _vp, _vp, _i, _i, _i, _vp],
+    "emb_head_ce_finish": [_vp, _vp, _vp, _vp, _vp, _i, _i, _vp],
     "emb_gather_rows": [_vp, _vp, _vp, _i, _vp, _i64, _i64, _vp],
     "emb_mt19937_shuffle": [_vp, _vp, _vp, _i64],
     "emb_reduce_defer": [_i],
@@ -89,7 +93,8 @@ def lib():
             fn.argtypes = argtypes
             fn.restype = {"emb_last_error": ctypes.c_char_p,
                           "emb_convblock_workspace_bytes": ctypes.c_int64,
-                          "emb_mlp_workspace_bytes": ctypes.c_int64}.get(name, ctypes.c_int)
+                          "emb_mlp_workspace_bytes": ctypes.c_int64,
+                          "emb_head_ce_workspace_bytes": ctypes.c_int64}.get(name, ctypes.c_int)
         if L.emb_abi_version() != 1:
             raise RuntimeError("libembrace_hip.so ABI version mismatch")
         _lib = L

@@ -8,11 +8,11 @@
 
 namespace emb {
 
-enum { RJ_LINEAR = 0, RJ_CONV = 1, RJ_MLP = 2 };
+enum { RJ_LINEAR = 0, RJ_CONV = 1, RJ_MLP = 2, RJ_HEAD_STATS = 3 };
 
 struct ReduceJob {
   const void* in;    // [S][per] partial sums (P-typed)
-  void* out[8];      // RJ_LINEAR: dW, db;  RJ_CONV: dW, dbias;  RJ_MLP: dW_0..3, db_0..3
+  void* out[8];      // RJ_LINEAR: dW, db;  RJ_CONV: dW, dbias;  RJ_MLP: dW_0..3, db_0..3;  RJ_HEAD_STATS: loss (float), confusion (int64[4])
   long per;
   int S, kind;
   int iv[9];         // RJ_LINEAR: N (row = [N values | bias]);  RJ_CONV: Cin, cin_pad, k;  RJ_MLP: L, N_0..3, K_0..3

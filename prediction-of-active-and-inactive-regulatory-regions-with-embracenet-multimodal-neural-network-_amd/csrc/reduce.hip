@@ -29,6 +29,9 @@ template <typename P> __device__ __forceinline__ void reduce_write(const ReduceJ
     const int tap = col / cin_pad, ci = col - tap * cin_pad;
     if (col == KK) ((P*)j.out[1])[o] = t;
     else if (ci < Cin) ((P*)j.out[0])[((long)o * Cin + ci) * k + tap] = t;
+  } else if (j.kind == RJ_HEAD_STATS) {   // head.hip: [loss share, tp, pp, positives, rows, -, -, -]; counts are small exact integers
+    if (q == 0) ((float*)j.out[0])[0] = (float)t;
+    else if (q <= 4 && j.out[1] != nullptr) ((long long*)j.out[1])[q - 1] = (long long)(t + (P)0.5);
   } else {                          // RJ_MLP: per layer [N*K weights | N biases]
     long off = q;
     const int L = j.iv[0];

@@ -191,7 +191,27 @@ class EmbraceNetMultimodal(nn.Module, _RngMixin):
             layers.append((lin.weight, lin.bias, relu, p, layer_id))
             i += 3 if relu else 1
             layer_id += 1
+        arm, self._fused_loss = getattr(self, "_fused_loss", None), None      # armed for ONE forward
+        if arm is not None:
+            if not self.fused_loss_ready(y.shape[0]):
+                raise RuntimeError("arm_fused_loss: check fused_loss_ready() first")
+            if len(layers) > 1:                                  # hidden post layers, then the head takes the loss with it
+                y = F_.mlp(y, layers[:-1], rng=rng, compute_dtype=T)
+            w, b = layers[-1][:2]
+            return F_.head_ce(y, w, b, arm, compute_dtype=T)
         return F_.mlp(y, layers, rng=rng, compute_dtype=T)
+
+    def fused_loss_ready(self, B):
+        """True when the final Linear(width, 2), the loss and the head's backward can run as ONE launch (csrc/head.hip):
+        fp32 / bf16 compute on fp32 masters.  A trainer then calls arm_fused_loss(functional.FusedLoss(...)) right before
+        the forward and ``logits.backward(<any tensor of that shape>)`` after it, instead of taking the loss itself."""
+        last = [m for m in self.post if isinstance(m, nn.Linear)][-1]
+        T = self.compute_dtype or last.weight.dtype
+        return last.weight.is_cuda and last.weight.dtype == torch.float32 and last.out_features == 2 and \
+            F_.head_ce_supported(B, last.in_features, T)
+
+    def arm_fused_loss(self, fused_loss):
+        self._fused_loss = fused_loss
 
     def forward(self, x, availabilities=None, selection_probabilities=None, is_training=False,
                 embracenet_dropout=True):

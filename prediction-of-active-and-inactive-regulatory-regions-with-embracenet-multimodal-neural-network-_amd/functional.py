@@ -425,6 +425,70 @@ def weighted_ce_with_grad(logits, target, class_counts=None, global_counts=False
     return loss.view(()), dz
 
 
+class FusedLoss:
+    """What the classifier head needs to take the loss (and its own backward) into its launch -- handed to the model for ONE
+    forward by a trainer (``EmbraceNetMultimodal.arm_fused_loss``): labels of the local rows, the class-count tensor
+    (filled by the kernel, or given when the counts are global), where to put the loss and the confusion counts, and the
+    step counters to advance (see weighted_ce_with_grad)."""
+    __slots__ = ("target", "class_counts", "global_counts", "loss_out", "confusion", "ticks")
+
+    def __init__(self, target, class_counts, global_counts, loss_out, confusion, ticks=()):
+        self.target, self.class_counts, self.global_counts = target, class_counts, bool(global_counts)
+        self.loss_out, self.confusion, self.ticks = loss_out, confusion, tuple(t for t in ticks if t is not None)
+
+
+def head_ce_supported(B, K, T):
+    return T in (torch.float32, torch.bfloat16) and bool(_lib.lib().emb_head_ce_supported(int(B), int(K), DTYPE_CODE[T]))
+
+
+class _HeadCEFn(torch.autograd.Function):
+    """logits = E W^T + b, the class-weighted CE on them, and the head's own backward, in one launch (csrc/head.hip).
+    The incoming gradient of `backward` is IGNORED: by contract the loss armed for this forward is the root of the graph
+    (trainers call ``logits.backward(<anything of the right shape>)``)."""
+
+    @staticmethod
+    def forward(ctx, E, W, b, T, arm, train):
+        _lib.require_cuda(E, W, b, arm.target)
+        L_ = _lib.lib()
+        B, K = E.shape
+        dev = E.device
+        Ec = _as(E, T)
+        if W.dtype != torch.float32 or b.dtype != torch.float32:
+            raise TypeError("fused head: fp32 master weights expected")
+        Wc, bc = W.detach().contiguous(), b.detach().contiguous()
+        tgt = _as(arm.target.reshape(-1), torch.int64)
+        logits = torch.empty(B, 2, dtype=T, device=dev)
+        dE = torch.empty(B, K, dtype=T, device=dev) if train else None
+        ws = _workspace(dev, L_.emb_head_ce_workspace_bytes(B, K), "head")
+        if len(arm.ticks) > 2:
+            raise ValueError("at most two tick counters")
+        ta, tb = (list(arm.ticks) + [None, None])[:2]
+        check(L_.emb_head_ce(ptr(Ec), ptr(Wc), ptr(bc), ptr(tgt), ptr(arm.class_counts), int(arm.global_counts), ptr(logits),
+                             ptr(dE), ptr(ws), ws.numel(), ptr(ta), ptr(tb), B, K, DTYPE_CODE[T], stream()), "emb_head_ce")
+        if not train:                                            # evaluation: nothing else will come, finish now
+            check(L_.emb_head_ce_finish(ptr(ws), None, None, ptr(arm.loss_out), ptr(arm.confusion), B, K, stream()), "emb_head_ce_finish")
+        ctx.keep = (dE, ws, arm.loss_out, arm.confusion, B, K, E.dtype)
+        ctx.sinks = (grad_sink(W, torch.float32), grad_sink(b, torch.float32))
+        return logits
+
+    @staticmethod
+    def backward(ctx, _ignored):
+        dE, ws, loss_out, confusion, B, K, edt = ctx.keep
+        dev = ws.device
+        dW = _out(ctx.sinks[0], (2, K), torch.float32, dev)
+        db = _out(ctx.sinks[1], (2,), torch.float32, dev)
+        check(_lib.lib().emb_head_ce_finish(ptr(ws), ptr(dW), ptr(db), ptr(loss_out), ptr(confusion), B, K, stream()), "emb_head_ce_finish")
+        return (dE if dE.dtype == edt else dE.to(edt), None if ctx.sinks[0] is not None else dW,
+                None if ctx.sinks[1] is not None else db, None, None, None)
+
+
+def head_ce(E, W, b, arm, compute_dtype=None):
+    """Final Linear(width, 2) + armed loss (FusedLoss) -> logits; see _HeadCEFn."""
+    # (needs_input_grad inside the node does not see torch.no_grad(): decide here whether a backward will follow)
+    train = torch.is_grad_enabled() and (E.requires_grad or W.requires_grad or b.requires_grad)
+    return _HeadCEFn.apply(E, W, b, compute_dtype or E.dtype, arm, train)
+
+
 def count_labels(target, out=None):
     tgt = _as(target.reshape(-1), torch.int64)
     _lib.require_cuda(tgt)

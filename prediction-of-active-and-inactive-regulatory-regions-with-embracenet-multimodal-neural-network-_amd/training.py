@@ -104,6 +104,7 @@ class StepRunner:
         self.model, self.optimizer, self.device = model, optimizer, device
         self.graph = GRAPH_STEPS if graph is None else bool(graph)
         self._graphs = {}
+        self.fuse_loss = True
         self.bucket = D.GradBucket(model.parameters()) if optimizer is not None else None
         self.counts = torch.zeros(2, dtype=torch.int64, device=device)
         on_gpu = torch.device(device).type == "cuda"
@@ -186,6 +187,12 @@ class StepRunner:
         prev = getattr(model, "defer_step_tick", False)
         if self.model_tick is not None:
             model.defer_step_tick = True                    # the loss kernel below advances the RNG step
+        loss_slot, count_slot = table.slot()
+        ticks = (self.model_tick, self.opt_tick if training else None)
+        # fp32 / bf16 runs: the classifier head takes the loss (and its own backward) into its launch (csrc/head.hip)
+        fused = self.fuse_loss and hasattr(model, "fused_loss_ready") and model.fused_loss_ready(x_1.shape[0])
+        if fused:
+            model.arm_fused_loss(F_.FusedLoss(tgt, self.counts, global_counts, loss_slot, count_slot, ticks))
         try:
             if training and _is_embracenet(model):
                 output = model([x_1, x_2], is_training=True)
@@ -194,8 +201,10 @@ class StepRunner:
         finally:
             if self.model_tick is not None:
                 model.defer_step_tick = prev
-        loss_slot, count_slot = table.slot()
-        ticks = (self.model_tick, self.opt_tick if training else None)
+            if fused:
+                model.arm_fused_loss(None)
+        if fused:
+            return output, loss_slot.view(()), None
         loss, dlogits = F_.weighted_ce_with_grad(output, tgt, class_counts=self.counts, global_counts=global_counts,
                                                  confusion=count_slot, loss_out=loss_slot, ticks=ticks)
         return output, loss, dlogits
@@ -218,7 +227,9 @@ class StepRunner:
         if deferred:
             F_.reduce_defer(True)       # the per-layer slab reductions of the backward are queued ...
         try:
-            output.backward(dlogits)    # the loss is the root of the graph: d loss / d logits comes from the loss kernel
+            # the loss is the root of the graph: d loss / d logits comes from the loss kernel (or, fused, is already inside
+            # the head's node, which ignores what it is handed)
+            output.backward(dlogits if dlogits is not None else output.detach())
         finally:
             if deferred:
                 F_.reduce_defer(False)
