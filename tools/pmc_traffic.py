@@ -9,13 +9,14 @@ Collect on the GPU box, one counter per pass (FETCH_SIZE and WRITE_SIZE do not f
 then here:  python tools/pmc_traffic.py gpurun_out/pmc_fetch gpurun_out/pmc_write [workload]
 
 Corrections as the guide prescribes for gfx950: counters are in KiB; FETCH_SIZE tallies 128-byte requests at 64 bytes,
-so it is doubled.  bytes per C-ABI call = (2*FETCH + WRITE) * 1024, summed over the kernels one call launches
-(emb_embrace_bwd = backward kernel + slab reduction)."""
+so it is doubled.  bytes per launch = (2*FETCH + WRITE) * 1024 per kernel (the slab reduction that completes an
+emb_embrace_bwd call outside a deferred backward pass is listed on its own)."""
 import csv, glob, json, os, sys
 from collections import defaultdict
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-GROUPS = {"embrace_fwd_kernel": ("embrace_fwd",), "embrace_bwd_kernel": ("embrace_bwd_kernel", "multi_reduce_kernel")}
+GROUPS = {"embrace_fwd_kernel": ("embrace_fwd",), "embrace_bwd_kernel": ("embrace_bwd_kernel",),
+          "embrace_bwd_slab_reduce": ("multi_reduce_kernel",)}
 
 
 def mean_counter(directory, counter):
@@ -46,8 +47,8 @@ def main():
     path = os.path.join(ROOT, "profiles", "pmc_traffic.json")
     doc = json.load(open(path)) if os.path.exists(path) else {}
     doc[workload] = out
-    doc["_note"] = ("bytes per C-ABI call = (2*FETCH_SIZE + WRITE_SIZE)*1024, FETCH_SIZE doubled per MI355X_MICROARCH.md (gfx950 "
-                    "tallies 128-B requests at 64 B); embrace_bwd = backward kernel + slab reduction kernel; tools/pmc_traffic.py")
+    doc["_note"] = ("bytes per launch = (2*FETCH_SIZE + WRITE_SIZE)*1024, FETCH_SIZE doubled per MI355X_MICROARCH.md (gfx950 "
+                    "tallies 128-B requests at 64 B); tools/pmc_traffic.py")
     doc["_raw_KiB"] = raw
     json.dump(doc, open(path, "w"), indent=1)
     print(json.dumps(doc, indent=1))
