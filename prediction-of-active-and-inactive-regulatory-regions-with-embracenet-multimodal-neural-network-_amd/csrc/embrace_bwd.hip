@@ -68,11 +68,11 @@ __global__ __launch_bounds__(kThreads, 2) void embrace_bwd_kernel(const T* __res
     const int wq = bid - dg1.end, sl = wq / wg1.tiles, tile = xcd_remap(wq % wg1.tiles, wg1.tiles);
     const GemmOperand<T> Bop{wg1.Bptr, nullptr, wg1.ldb, wg1.vec_b != 0};
     if (wg1.S == 1) {
-      gemm_tile<CW>(A, Bop, wg1.M, wg1.N, wg1.K, tile / wg1.tiles_n, tile % wg1.tiles_n, XfEmbraceMask{(uint8_t)wg1.want},
+      gemm_tile<CW>(A, Bop, wg1.M, wg1.N, wg1.K, tile % (wg1.tiles / wg1.tiles_n), tile / (wg1.tiles / wg1.tiles_n), XfEmbraceMask{(uint8_t)wg1.want},
                     wg1.N, EpiStore<P>{wg1.C, (long)wg1.N, wg1.extra, wg1.N, wg1.vec_c != 0}, arena);
     } else {   // batch slice sl: partial sums (bias column included) to this slice's slab
       const int k_begin = sl * wg1.kper, k_end = min(wg1.K, k_begin + wg1.kper);
-      gemm_tile<CW>(A, Bop, wg1.M, wg1.N, k_end, tile / wg1.tiles_n, tile % wg1.tiles_n, XfEmbraceMask{(uint8_t)wg1.want},
+      gemm_tile<CW>(A, Bop, wg1.M, wg1.N, k_end, tile % (wg1.tiles / wg1.tiles_n), tile / (wg1.tiles / wg1.tiles_n), XfEmbraceMask{(uint8_t)wg1.want},
                     wg1.N, EpiStore<P>{wg1.slab + (long)sl * wg1.M * (wg1.N + 1), (long)(wg1.N + 1), nullptr, wg1.N + 1, false},
                     arena, k_begin);
     }
@@ -85,11 +85,11 @@ __global__ __launch_bounds__(kThreads, 2) void embrace_bwd_kernel(const T* __res
     const int wq = bid - dg0.end, sl = wq / wg0.tiles, tile = xcd_remap(wq % wg0.tiles, wg0.tiles);
     const GemmOperand<T> Bop{wg0.Bptr, nullptr, wg0.ldb, wg0.vec_b != 0};
     if (wg0.S == 1) {
-      gemm_tile<CW>(A, Bop, wg0.M, wg0.N, wg0.K, tile / wg0.tiles_n, tile % wg0.tiles_n, XfEmbraceMask{(uint8_t)wg0.want},
+      gemm_tile<CW>(A, Bop, wg0.M, wg0.N, wg0.K, tile % (wg0.tiles / wg0.tiles_n), tile / (wg0.tiles / wg0.tiles_n), XfEmbraceMask{(uint8_t)wg0.want},
                     wg0.N, EpiStore<P>{wg0.C, (long)wg0.N, wg0.extra, wg0.N, wg0.vec_c != 0}, arena);
     } else {   // batch slice sl: partial sums (bias column included) to this slice's slab
       const int k_begin = sl * wg0.kper, k_end = min(wg0.K, k_begin + wg0.kper);
-      gemm_tile<CW>(A, Bop, wg0.M, wg0.N, k_end, tile / wg0.tiles_n, tile % wg0.tiles_n, XfEmbraceMask{(uint8_t)wg0.want},
+      gemm_tile<CW>(A, Bop, wg0.M, wg0.N, k_end, tile % (wg0.tiles / wg0.tiles_n), tile / (wg0.tiles / wg0.tiles_n), XfEmbraceMask{(uint8_t)wg0.want},
                     wg0.N, EpiStore<P>{wg0.slab + (long)sl * wg0.M * (wg0.N + 1), (long)(wg0.N + 1), nullptr, wg0.N + 1, false},
                     arena, k_begin);
     }
