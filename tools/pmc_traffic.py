@@ -9,14 +9,13 @@ Collect on the GPU box, one counter per pass (FETCH_SIZE and WRITE_SIZE do not f
 then here:  python tools/pmc_traffic.py gpurun_out/pmc_fetch gpurun_out/pmc_write [workload]
 
 Corrections as the guide prescribes for gfx950: counters are in KiB; FETCH_SIZE tallies 128-byte requests at 64 bytes,
-so it is doubled.  bytes per launch = (2*FETCH + WRITE) * 1024 per kernel (the slab reduction that completes an
-emb_embrace_bwd call outside a deferred backward pass is listed on its own)."""
+so it is doubled.  bytes per launch = (2*FETCH + WRITE) * 1024 per kernel (the slab reductions are queued in that run
+and flushed in one launch at its end, so they have no per-call figure here)."""
 import csv, glob, json, os, sys
 from collections import defaultdict
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-GROUPS = {"embrace_fwd_kernel": ("embrace_fwd",), "embrace_bwd_kernel": ("embrace_bwd_kernel",),
-          "embrace_bwd_slab_reduce": ("multi_reduce_kernel",)}
+GROUPS = {"embrace_fwd_kernel": ("embrace_fwd",), "embrace_bwd_kernel": ("embrace_bwd_kernel",)}
 
 
 def mean_counter(directory, counter):
