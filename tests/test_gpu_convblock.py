@@ -45,6 +45,7 @@ CASES = [
     ("one", 37, [(4, 16, 5)]),
     ("deep", 16, [(4, 32, 5), (32, 32, 5), (32, 128, 11), (128, 128, 15)]),   # BASELINE cfg4 stack, L: 256..8
     ("odd", 9, [(4, 96, 11), (96, 64, 5)]),
+    ("wide", 6, [(4, 64, 5), (64, 96, 11), (96, 256, 5), (256, 512, 15)]),   # widest channel choices of the search space
     # shorter windows: several whole sequences per 256-row tile of the fused first block, last tile partly filled
     ("short100", 9, [(4, 64, 15), (64, 32, 5)], 100),
     ("short37", 21, [(4, 16, 5)], 37),

@@ -6,6 +6,8 @@ reference's order and injects them, so the index tensor must be bit-exact and ev
 rounding.  Tolerances: fp64 models 1e-9 (logits) / 1e-8 relative (gradients through the fp32 loss: 1e-5 relative; trained parameters 1e-6);
 fp32 models 1e-5 on logits (the north-star bar).
 """
+import copy
+
 import numpy as np
 import pytest
 import torch
@@ -233,3 +235,60 @@ def test_g10_inference_twin_matches_reference(ea, i, tmp_path):
     torch.manual_seed(case["seed"] + 1)
     p1 = twin.predict_proba(x1.cpu(), x2.cpu(), batch_size=N)
     assert np.abs(p1.cpu().numpy() - g[case["key"] + "_batched"].reshape(N, 2)[:, 1]).max() < 1e-9
+
+
+class _RandomTrial:
+    """Draws every hyper-parameter the model asks for uniformly from the range / choices it offers (the reference's Optuna
+    search space, whatever it is: FFNN depth and widths, CNN depth, channels, kernel sizes, dropouts, embracement size,
+    post stack)."""
+
+    def __init__(self, seed):
+        self.rng, self.asked = np.random.RandomState(seed), {}
+
+    def suggest_int(self, name, lo, hi):
+        self.asked[name] = int(self.rng.randint(lo, hi + 1))
+        return self.asked[name]
+
+    def suggest_categorical(self, name, choices):
+        self.asked[name] = choices[int(self.rng.randint(len(choices)))]
+        return self.asked[name]
+
+    def suggest_float(self, name, lo, hi):
+        self.asked[name] = float(self.rng.uniform(lo, hi))
+        return self.asked[name]
+
+
+@pytest.mark.parametrize("seed", range(24))
+def test_random_points_of_the_search_space(ea, seed):
+    """Shape coverage: two dozen random architectures of the reference's search space.  (1) fp64 eval logits of the HIP path
+    equal the same module run on stock torch operators (use_hip = False for the pre-nets, fusion still HIP) to 1e-9;
+    (2) fp32 and bf16 training steps through StepRunner (fused head where its shape rules allow, three launches otherwise)
+    run, give finite losses and move the parameters."""
+    from embracenet_amd import optim, training
+    F_in = [48, 152, 429, 562][seed % 4]
+    B = [32, 37, 64, 100][seed % 4]
+    x1, x2, y = model_batch(f"rs/{seed}", B, F_in, 0.3)
+    trial = _RandomTrial(100 + seed)
+    model = ea.EmbraceNetMultimodal(trial, cell_line="A549", task="active_E_vs_inactive_E", device=DEV, in_features_FFNN=F_in)
+    model = model.double().to(DEV).set_rng("host")
+    model.eval()
+    a, b = torch.from_numpy(x1).to(DEV), torch.from_numpy(x2).to(DEV)
+    with torch.no_grad():
+        torch.manual_seed(5); z_hip = model([a, b])
+        model.FFNN.use_hip = model.CNN.use_hip = False
+        torch.manual_seed(5); z_ref = model([a, b])
+        model.FFNN.use_hip = model.CNN.use_hip = True
+    assert (z_hip - z_ref).abs().max().item() < 1e-9 * max(1.0, z_ref.abs().max().item()), trial.asked
+    for precision in ("float32", "bfloat16"):
+        m = training.prepare_model(copy.deepcopy(model), DEV, precision).set_rng("philox", seed=seed)
+        opt = optim.Adam(m.parameters(), lr=1e-3)
+        runner = training.StepRunner(m, opt, DEV)
+        table = ea.metrics.StepTable(4, DEV)
+        before = m.embracenet.docking_0.weight.detach().clone()
+        m.train()
+        for _ in range(2):
+            runner.train_step(torch.from_numpy(x1).float(), torch.from_numpy(x2).float(), torch.from_numpy(y), table)
+        losses, counts = table.fetch()
+        assert np.isfinite(losses).all() and (losses > 0).all(), (precision, trial.asked, losses)
+        assert counts[:, 3].tolist() == [B, B] and counts[:, 2].tolist() == [int(y.sum())] * 2
+        assert not torch.equal(before, m.embracenet.docking_0.weight), (precision, trial.asked)
