@@ -242,10 +242,12 @@ class EmbraceNetMultimodal(nn.Module, _RngMixin):
         if T == torch.bfloat16 and not (self.FFNN.use_hip and self.CNN.use_hip):
             with torch.autocast("cuda", dtype=torch.bfloat16):          # stock-operator A/B path only
                 h0, h1 = self.FFNN(x_FFNN, rng=rng), self.CNN(x_CNN, rng=rng)
-        elif x_FFNN.is_cuda and getattr(self, "overlap_prenets", True) and not os.environ.get("EMB_NO_OVERLAP"):
-            # the two pre-networks are independent: the (tiny, launch-latency bound) epigenomic MLP and the selection
-            # cdf run on a side stream next to the sequence CNN.  autograd replays each node on its forward stream, so the
-            # two backward chains overlap as well; fork/join by events, which a stream capture records as graph edges
+        elif x_FFNN.is_cuda and (getattr(self, "overlap_prenets", False) or os.environ.get("EMB_OVERLAP_PRENETS")):
+            # OPT-IN (model.overlap_prenets = True): the two pre-networks are independent, so the epigenomic MLP and the
+            # selection cdf can run on a side stream next to the sequence CNN (autograd replays each node on its forward
+            # stream, so the backward chains overlap as well; fork/join by events = graph edges under capture).  It paid
+            # while those kernels were slow; with the fused MLP kernels the four fork/join edges cost more than the
+            # ~28 us they hide (measured 0.288 vs 0.280 ms/step in favour of ONE stream), hence off by default
             cur = torch.cuda.current_stream(dev)
             side = self._side_stream(dev)
             side.wait_stream(cur)
