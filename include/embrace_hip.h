@@ -76,6 +76,13 @@ int emb_embrace_fwd(const void* X0, const void* X1, const void* W0, const void* 
                     const void* b1, const float* cdf0, const double* u, uint64_t seed, uint64_t step_val,
                     const uint64_t* step_dev, int64_t row0, void* E, uint8_t* code, int B, int d0, int d1,
                     int c, int dtype, emb_stream_t stream);
+/* The same with the selection threshold of every row computed inside the launch from (p, avail, device_dropout) -- the
+ * arguments and arithmetic of emb_select_prep, *status as there -- so that EmbraceNet.forward (:34-90) is ONE kernel. */
+int emb_embrace_fwd_select(const void* X0, const void* X1, const void* W0, const void* b0, const void* W1,
+                           const void* b1, const float* p, int p_rows, const float* avail, int device_dropout,
+                           int32_t* status, const double* u, uint64_t seed, uint64_t step_val, const uint64_t* step_dev,
+                           int64_t row0, void* E, uint8_t* code, int B, int d0, int d1, int c, int dtype,
+                           emb_stream_t stream);
 
 /* autograd of the above (loss.backward(), utils/training_models_multimodal.py:156):
  *   dD_m = dE * [idx == m] * [pre_m > 0];  dW_m = dD_m^T X_m;  db_m = sum_b dD_m;  dX_m = dD_m W_m

@@ -30,6 +30,7 @@ SIGNATURES = {
     "emb_last_error": [],
     "emb_select_prep": [_vp, _i, _vp, _i, _u64, _u64, _vp, _i64, _vp, _vp, _i, _vp],
     "emb_embrace_fwd": [_vp] * 8 + [_u64, _u64, _vp, _i64, _vp, _vp, _i, _i, _i, _i, _i, _vp],
+    "emb_embrace_fwd_select": [_vp] * 7 + [_i, _vp, _i, _vp, _vp, _u64, _u64, _vp, _i64, _vp, _vp, _i, _i, _i, _i, _i, _vp],
     "emb_embrace_bwd": [_vp] * 12 + [_vp, _i64, _i, _i, _i, _i, _i, _vp],
     "emb_linear_fwd": [_vp] * 5 + [_i, _f, _i, _u64, _u64, _vp, _i64, _i, _i, _i, _i, _vp],
     "emb_linear_bwd": [_vp] * 7 + [_i, _f, _vp, _i64, _i, _i, _i, _i, _vp],

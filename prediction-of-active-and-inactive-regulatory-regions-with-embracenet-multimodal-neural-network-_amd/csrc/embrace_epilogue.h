@@ -6,23 +6,69 @@
 
 namespace emb {
 
+// Where the selection threshold of a row comes from: a cdf0[B] vector made earlier (emb_select_prep; the host-replay parity
+// mode needs it on its own), or -- cdf0 == NULL -- computed here from the selection probabilities, so that the forward pass
+// is ONE launch (emb_embrace_fwd_select).  Same arithmetic either way (select_cdf).
+struct SelArgs {
+  const float* cdf0;
+  const float* p;        // [p_rows][2]
+  const float* avail;    // [B][2] or NULL
+  int32_t* status;
+  int p_rows, device_dropout;
+};
+
+// EmbraceNetMultimodal.py:63-76, :178-184 and the cdf torch.multinomial builds from the row.
+__device__ __forceinline__ float select_cdf(const SelArgs& s, int row, uint64_t seed, uint64_t step, int64_t grow0, bool* ok) {
+  const float* pr = s.p + (s.p_rows == 1 ? 0 : 2 * (long)row);
+  float a0 = 1.0f, a1 = 1.0f;
+  if (s.device_dropout) {
+    const float gate = uniform24(philox4x32_10(seed, rng_stream(step, EMB_RNG_GATE), 0).x);
+    if (gate >= 0.5f) {   // EmbraceNetMultimodal.py:180
+      const float t = uniform24(philox4x32_10(seed, rng_stream(step, EMB_RNG_ROWMOD), (uint64_t)(grow0 + row)).x);
+      const bool m1 = t > 0.5f;   // torch.round: half-to-even, 0.5 -> 0   (:181)
+      a0 = m1 ? 0.0f : 1.0f;
+      a1 = m1 ? 1.0f : 0.0f;
+    }
+  } else if (s.avail != nullptr) {
+    a0 = s.avail[2 * (long)row];
+    a1 = s.avail[2 * (long)row + 1];
+  }
+  // every operation below is a separately rounded fp32 op, as in the reference's ATen calls
+  const float q0 = __fmul_rn(pr[0], a0), q1 = __fmul_rn(pr[1], a1);   // :73
+  const float sm = __fadd_rn(q0, q1);                                  // :75
+  const float n0 = __fdiv_rn(q0, sm), n1 = __fdiv_rn(q1, sm);          // :76
+  // torch.multinomial (ATen CPU kernel): running sum, then cum /= sum
+  const float tot = __fadd_rn(n0, n1);
+  const float cdf = __fdiv_rn(n0, tot);
+  *ok = (n0 >= 0.0f) && (n1 >= 0.0f) && isfinite(n0) && isfinite(n1) && (tot > 0.0f);
+  return *ok ? cdf : __builtin_nanf("");
+}
+
 template <class Cfg>
 __device__ __forceinline__ void embrace_epilogue(const typename Cfg::M::Acc* cs0, const typename Cfg::M::Acc* cs1,
                                                  const typename Cfg::M::Acc* __restrict__ b0,
-                                                 const typename Cfg::M::Acc* __restrict__ b1, const float* __restrict__ cdf0,
+                                                 const typename Cfg::M::Acc* __restrict__ b1, const SelArgs sel,
                                                  const double* __restrict__ u, uint64_t seed, uint64_t step_val,
                                                  const uint64_t* __restrict__ step_dev, int64_t grow0,
                                                  typename Cfg::T* __restrict__ E, uint8_t* __restrict__ code, int B, int c,
                                                  int row0, int col0, bool vec_c) {
   using T = typename Cfg::T;
   using Acc = typename Cfg::M::Acc;
-  const uint64_t stream = rng_stream(step_val + (step_dev ? *step_dev : 0), EMB_RNG_SELECT);
+  const uint64_t step = step_val + (step_dev ? *step_dev : 0);
+  const uint64_t stream = rng_stream(step, EMB_RNG_SELECT);
   constexpr int GROUPS = Cfg::BM * Cfg::BN / 4;
   for (int gidx = threadIdx.x; gidx < GROUPS; gidx += kThreads) {
     const int r = gidx / (Cfg::BN / 4), cq = (gidx % (Cfg::BN / 4)) * 4;
     const int row = row0 + r, col = col0 + cq;
     if (row >= B || col >= c) continue;
-    const double thr = (double)cdf0[row];
+    double thr;
+    if (sel.cdf0 != nullptr) {
+      thr = (double)sel.cdf0[row];
+    } else {
+      bool ok;
+      thr = (double)select_cdf(sel, row, seed, step, grow0, &ok);
+      if (!ok && col == 0) atomicOr(sel.status, EMB_STATUS_INVALID_DISTRIBUTION);   // (one column group per row reports)
+    }
     const long base = (long)row * c + col;
     const int nval = min(4, c - col);
     double uu[4];

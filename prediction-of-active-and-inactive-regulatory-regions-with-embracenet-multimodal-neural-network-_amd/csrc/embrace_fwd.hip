@@ -16,7 +16,7 @@ __global__ __launch_bounds__(kThreads, 2) void embrace_fwd_kernel(
     const typename Cfg::T* __restrict__ X0, const typename Cfg::T* __restrict__ X1,
     const typename Cfg::T* __restrict__ W0, const typename Cfg::T* __restrict__ W1,
     const typename Cfg::M::Acc* __restrict__ b0, const typename Cfg::M::Acc* __restrict__ b1,
-    const float* __restrict__ cdf0, const double* __restrict__ u, uint64_t seed, uint64_t step_val,
+    const SelArgs sel, const double* __restrict__ u, uint64_t seed, uint64_t step_val,
     const uint64_t* __restrict__ step_dev, int64_t grow0, typename Cfg::T* __restrict__ E,
     uint8_t* __restrict__ code, int B, int d0, int d1, int c, int tiles_n, int ntiles, bool vec0, bool vec1,
     bool vec_c) {
@@ -47,10 +47,10 @@ __global__ __launch_bounds__(kThreads, 2) void embrace_fwd_kernel(
   reduce_to_slab<Cfg>(acc0, cs0);
   reduce_to_slab<Cfg>(acc1, cs1);
 
-  embrace_epilogue<Cfg>(cs0, cs1, b0, b1, cdf0, u, seed, step_val, step_dev, grow0, E, code, B, c, row0, col0, vec_c);
+  embrace_epilogue<Cfg>(cs0, cs1, b0, b1, sel, u, seed, step_val, step_dev, grow0, E, code, B, c, row0, col0, vec_c);
 }
 
-// EmbraceNetMultimodal.py:63-76, :178-184 and the cdf torch.multinomial builds from the row.
+// the selection cdf as a vector of its own (embrace_epilogue.h: select_cdf)
 __global__ __launch_bounds__(kThreads) void select_prep_kernel(const float* __restrict__ p, int p_rows,
                                                                const float* __restrict__ avail, int device_dropout,
                                                                uint64_t seed, uint64_t step_val,
@@ -59,39 +59,16 @@ __global__ __launch_bounds__(kThreads) void select_prep_kernel(const float* __re
                                                                int B) {
   const int row = blockIdx.x * blockDim.x + threadIdx.x;
   if (row >= B) return;
-  const float* pr = p + (p_rows == 1 ? 0 : 2 * (long)row);
-  float a0 = 1.0f, a1 = 1.0f;
-  if (device_dropout) {
-    const uint64_t step = step_val + (step_dev ? *step_dev : 0);
-    const float gate = uniform24(philox4x32_10(seed, rng_stream(step, EMB_RNG_GATE), 0).x);
-    if (gate >= 0.5f) {   // EmbraceNetMultimodal.py:180
-      const float t = uniform24(philox4x32_10(seed, rng_stream(step, EMB_RNG_ROWMOD), (uint64_t)(grow0 + row)).x);
-      const bool m1 = t > 0.5f;   // torch.round: half-to-even, 0.5 -> 0   (:181)
-      a0 = m1 ? 0.0f : 1.0f;
-      a1 = m1 ? 1.0f : 0.0f;
-    }
-  } else if (avail != nullptr) {
-    a0 = avail[2 * (long)row];
-    a1 = avail[2 * (long)row + 1];
-  }
-  // every operation below is a separately rounded fp32 op, as in the reference's ATen calls
-  const float q0 = __fmul_rn(pr[0], a0), q1 = __fmul_rn(pr[1], a1);   // :73
-  const float s = __fadd_rn(q0, q1);                                   // :75
-  const float n0 = __fdiv_rn(q0, s), n1 = __fdiv_rn(q1, s);            // :76
-  // torch.multinomial (ATen CPU kernel): running sum, then cum /= sum
-  const float tot = __fadd_rn(n0, n1);
-  float cdf = __fdiv_rn(n0, tot);
-  const bool ok = (n0 >= 0.0f) && (n1 >= 0.0f) && isfinite(n0) && isfinite(n1) && (tot > 0.0f);
-  if (!ok) {
-    cdf = __builtin_nanf("");
-    atomicOr(status, EMB_STATUS_INVALID_DISTRIBUTION);
-  }
+  const SelArgs sel{nullptr, p, avail, status, p_rows, device_dropout};
+  bool ok;
+  const float cdf = select_cdf(sel, row, seed, step_val + (step_dev ? *step_dev : 0), grow0, &ok);
+  if (!ok) atomicOr(status, EMB_STATUS_INVALID_DISTRIBUTION);
   cdf0[row] = cdf;
 }
 
 // ----------------------------------------------------------------------------------- dispatch
 template <class Cfg> static int launch_fwd(const void* X0, const void* X1, const void* W0, const void* b0, const void* W1,
-                                           const void* b1, const float* cdf0, const double* u, uint64_t seed,
+                                           const void* b1, const SelArgs& sel, const double* u, uint64_t seed,
                                            uint64_t step_val, const uint64_t* step_dev, int64_t row0, void* E, uint8_t* code,
                                            int B, int d0, int d1, int c, hipStream_t s) {
   using T = typename Cfg::T;
@@ -109,7 +86,7 @@ template <class Cfg> static int launch_fwd(const void* X0, const void* X1, const
     attr_set = true;
   }
   embrace_fwd_kernel<Cfg><<<ntiles, kThreads, lds, s>>>(
-      (const T*)X0, (const T*)X1, (const T*)W0, (const T*)W1, (const Acc*)b0, (const Acc*)b1, cdf0, u, seed, step_val,
+      (const T*)X0, (const T*)X1, (const T*)W0, (const T*)W1, (const Acc*)b0, (const Acc*)b1, sel, u, seed, step_val,
       step_dev, row0, (T*)E, code, B, d0, d1, c, tiles_n, ntiles, vec0, vec1, vec_c);
   EMB_CHECK_LAUNCH();
   return EMB_OK;
@@ -132,17 +109,17 @@ template <> struct FwdCfg<__bf16> {
 };
 
 template <typename T> static int fwd_dispatch(const void* X0, const void* X1, const void* W0, const void* b0, const void* W1,
-                                              const void* b1, const float* cdf0, const double* u, uint64_t seed,
+                                              const void* b1, const SelArgs& sel, const double* u, uint64_t seed,
                                               uint64_t step_val, const uint64_t* step_dev, int64_t row0, void* E,
                                               uint8_t* code, int B, int d0, int d1, int c, hipStream_t s) {
   const long tiles_L = (long)cdiv(B, 64) * cdiv(c, 64);
   if (tiles_L < 192) {   // small B*c, long K: operands streamed straight into MFMA fragments, K split over the 4 waves
-    const int rc = launch_embrace_fwd_stream<T>(X0, X1, W0, b0, W1, b1, cdf0, u, seed, step_val, step_dev, row0, E, code, B, d0, d1, c, s);
+    const int rc = launch_embrace_fwd_stream<T>(X0, X1, W0, b0, W1, b1, sel, u, seed, step_val, step_dev, row0, E, code, B, d0, d1, c, s);
     if (rc != 1) return rc;
   }
   if (tiles_L >= 192)
-    return launch_fwd<typename FwdCfg<T>::L>(X0, X1, W0, b0, W1, b1, cdf0, u, seed, step_val, step_dev, row0, E, code, B, d0, d1, c, s);
-  return launch_fwd<typename FwdCfg<T>::S>(X0, X1, W0, b0, W1, b1, cdf0, u, seed, step_val, step_dev, row0, E, code, B, d0, d1, c, s);
+    return launch_fwd<typename FwdCfg<T>::L>(X0, X1, W0, b0, W1, b1, sel, u, seed, step_val, step_dev, row0, E, code, B, d0, d1, c, s);
+  return launch_fwd<typename FwdCfg<T>::S>(X0, X1, W0, b0, W1, b1, sel, u, seed, step_val, step_dev, row0, E, code, B, d0, d1, c, s);
 }
 
 }  // namespace emb
@@ -159,19 +136,41 @@ extern "C" int emb_select_prep(const float* p, int p_rows, const float* avail, i
   return EMB_OK;
 }
 
+static int embrace_fwd_entry(const char* who, const void* X0, const void* X1, const void* W0, const void* b0, const void* W1,
+                             const void* b1, const emb::SelArgs& sel, const double* u, uint64_t seed, uint64_t step_val,
+                             const uint64_t* step_dev, int64_t row0, void* E, uint8_t* code, int B, int d0, int d1, int c, int dtype,
+                             emb_stream_t stream) {
+  EMB_CHECK_ARG(X0 && X1 && W0 && W1 && b0 && b1 && E && code, "%s: null pointer", who);
+  EMB_CHECK_ARG(B >= 0 && d0 > 0 && d1 > 0 && c > 0, "%s: bad dims B=%d d0=%d d1=%d c=%d", who, B, d0, d1, c);
+  if (B == 0) return EMB_OK;
+  hipStream_t s = (hipStream_t)stream;
+  switch (dtype) {
+    case EMB_F32: return emb::fwd_dispatch<float>(X0, X1, W0, b0, W1, b1, sel, u, seed, step_val, step_dev, row0, E, code, B, d0, d1, c, s);
+    case EMB_BF16: return emb::fwd_dispatch<__bf16>(X0, X1, W0, b0, W1, b1, sel, u, seed, step_val, step_dev, row0, E, code, B, d0, d1, c, s);
+    case EMB_F64: return emb::fwd_dispatch<double>(X0, X1, W0, b0, W1, b1, sel, u, seed, step_val, step_dev, row0, E, code, B, d0, d1, c, s);
+  }
+  emb::set_error("%s: unsupported dtype %d", who, dtype);
+  return EMB_ERR_DTYPE;
+}
+
 extern "C" int emb_embrace_fwd(const void* X0, const void* X1, const void* W0, const void* b0, const void* W1,
                                const void* b1, const float* cdf0, const double* u, uint64_t seed, uint64_t step_val,
                                const uint64_t* step_dev, int64_t row0, void* E, uint8_t* code, int B, int d0, int d1, int c,
                                int dtype, emb_stream_t stream) {
-  EMB_CHECK_ARG(X0 && X1 && W0 && W1 && b0 && b1 && cdf0 && E && code, "emb_embrace_fwd: null pointer");
-  EMB_CHECK_ARG(B >= 0 && d0 > 0 && d1 > 0 && c > 0, "emb_embrace_fwd: bad dims B=%d d0=%d d1=%d c=%d", B, d0, d1, c);
-  if (B == 0) return EMB_OK;
-  hipStream_t s = (hipStream_t)stream;
-  switch (dtype) {
-    case EMB_F32: return emb::fwd_dispatch<float>(X0, X1, W0, b0, W1, b1, cdf0, u, seed, step_val, step_dev, row0, E, code, B, d0, d1, c, s);
-    case EMB_BF16: return emb::fwd_dispatch<__bf16>(X0, X1, W0, b0, W1, b1, cdf0, u, seed, step_val, step_dev, row0, E, code, B, d0, d1, c, s);
-    case EMB_F64: return emb::fwd_dispatch<double>(X0, X1, W0, b0, W1, b1, cdf0, u, seed, step_val, step_dev, row0, E, code, B, d0, d1, c, s);
-  }
-  emb::set_error("emb_embrace_fwd: unsupported dtype %d", dtype);
-  return EMB_ERR_DTYPE;
+  EMB_CHECK_ARG(cdf0, "emb_embrace_fwd: null pointer");
+  const emb::SelArgs sel{cdf0, nullptr, nullptr, nullptr, 0, 0};
+  return embrace_fwd_entry("emb_embrace_fwd", X0, X1, W0, b0, W1, b1, sel, u, seed, step_val, step_dev, row0, E, code, B, d0, d1, c,
+                           dtype, stream);
+}
+
+extern "C" int emb_embrace_fwd_select(const void* X0, const void* X1, const void* W0, const void* b0, const void* W1,
+                                      const void* b1, const float* p, int p_rows, const float* avail, int device_dropout,
+                                      int32_t* status, const double* u, uint64_t seed, uint64_t step_val,
+                                      const uint64_t* step_dev, int64_t row0, void* E, uint8_t* code, int B, int d0, int d1,
+                                      int c, int dtype, emb_stream_t stream) {
+  EMB_CHECK_ARG(p && status, "emb_embrace_fwd_select: null pointer");
+  EMB_CHECK_ARG(p_rows == 1 || p_rows == B, "emb_embrace_fwd_select: p_rows must be 1 or B (got %d, B=%d)", p_rows, B);
+  const emb::SelArgs sel{nullptr, p, avail, status, p_rows, device_dropout};
+  return embrace_fwd_entry("emb_embrace_fwd_select", X0, X1, W0, b0, W1, b1, sel, u, seed, step_val, step_dev, row0, E, code, B, d0,
+                           d1, c, dtype, stream);
 }

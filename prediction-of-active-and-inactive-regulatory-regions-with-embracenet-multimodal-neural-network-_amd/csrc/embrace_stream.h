@@ -97,7 +97,7 @@ __device__ __forceinline__ void stream_mma(int nk, int j0, const typename Vec16<
 template <typename T>
 __global__ __launch_bounds__(kThreads, 2) void embrace_fwd_stream_kernel(
     const T* __restrict__ X0, const T* __restrict__ X1, const T* __restrict__ W0, const T* __restrict__ W1,
-    const typename AccOf<T>::type* __restrict__ b0, const typename AccOf<T>::type* __restrict__ b1, const float* __restrict__ cdf0,
+    const typename AccOf<T>::type* __restrict__ b0, const typename AccOf<T>::type* __restrict__ b1, const SelArgs sel,
     const double* __restrict__ u, uint64_t seed, uint64_t step_val, const uint64_t* __restrict__ step_dev, int64_t grow0,
     T* __restrict__ E, uint8_t* __restrict__ code, int B, int d0, int d1, int c, int tiles_n, int ntiles, bool vec_c) {
   using Cfg = typename StreamCfg<T>::type;
@@ -146,13 +146,13 @@ __global__ __launch_bounds__(kThreads, 2) void embrace_fwd_stream_kernel(
     part[0][m][idx] = ((part[0][m][idx] + part[1][m][idx]) + part[2][m][idx]) + part[3][m][idx];
   }
   __syncthreads();
-  embrace_epilogue<Cfg>(part[0][0], part[0][1], b0, b1, cdf0, u, seed, step_val, step_dev, grow0, E, code, B, c, row0, col0, vec_c);
+  embrace_epilogue<Cfg>(part[0][0], part[0][1], b0, b1, sel, u, seed, step_val, step_dev, grow0, E, code, B, c, row0, col0, vec_c);
 }
 
 // returns 1 when the shapes do not qualify (caller uses the LDS-tiled kernel)
 template <typename T>
 static int launch_embrace_fwd_stream(const void* X0, const void* X1, const void* W0, const void* b0, const void* W1, const void* b1,
-                                     const float* cdf0, const double* u, uint64_t seed, uint64_t step_val, const uint64_t* step_dev,
+                                     const SelArgs& sel, const double* u, uint64_t seed, uint64_t step_val, const uint64_t* step_dev,
                                      int64_t row0, void* E, uint8_t* code, int B, int d0, int d1, int c, hipStream_t s) {
   using Acc = typename AccOf<T>::type;
   constexpr int VEC = Elem<T>::VEC;
@@ -160,7 +160,7 @@ static int launch_embrace_fwd_stream(const void* X0, const void* X1, const void*
   const int tiles_n = cdiv(c, kSN), ntiles = cdiv(B, kSM) * tiles_n;
   const bool vec_c = (c % 4 == 0) && aligned16(E) && aligned16(u) && ((reinterpret_cast<uintptr_t>(code) & 3u) == 0);
   embrace_fwd_stream_kernel<T><<<ntiles, kThreads, 0, s>>>((const T*)X0, (const T*)X1, (const T*)W0, (const T*)W1, (const Acc*)b0,
-                                                          (const Acc*)b1, cdf0, u, seed, step_val, step_dev, row0, (T*)E, code, B, d0,
+                                                          (const Acc*)b1, sel, u, seed, step_val, step_dev, row0, (T*)E, code, B, d0,
                                                           d1, c, tiles_n, ntiles, vec_c);
   EMB_CHECK_LAUNCH();
   return EMB_OK;

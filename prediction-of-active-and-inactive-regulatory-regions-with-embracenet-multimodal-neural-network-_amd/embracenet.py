@@ -92,6 +92,17 @@ class EmbraceNet(nn.Module, _RngMixin):
             self._status = torch.zeros(1, dtype=torch.int32, device=dev)       # sticky bits, cleared when read
         return F_.select_prep(p, avail, B, rng=rng, device_dropout=_device_dropout, status=self._status)
 
+    def _select_inline(self, B, dev, availabilities, selection_probabilities, _device_dropout):
+        if selection_probabilities is None:                       # :70-71
+            selection_probabilities = torch.ones(1, 2, dtype=torch.float32, device=dev)
+        p = selection_probabilities.to(device=dev, dtype=torch.float32)
+        if p.dim() == 2 and p.shape[0] not in (1, B):
+            raise ValueError("selection_probabilities must be [B, M] or [M]")
+        avail = None if availabilities is None else availabilities.to(device=dev, dtype=torch.float32)
+        if getattr(self, "_status", None) is None or self._status.device != dev:
+            self._status = torch.zeros(1, dtype=torch.int32, device=dev)       # sticky bits, cleared when read
+        return F_.SelectInline(p, avail, _device_dropout, self._status), self._status
+
     def forward(self, input_list, availabilities=None, selection_probabilities=None, _device_dropout=False,
                 _advance=True, _prep=None):
         assert len(input_list) == len(self.input_size_list)
@@ -104,13 +115,17 @@ class EmbraceNet(nn.Module, _RngMixin):
         dev = x0.device
         T = self.compute_dtype or self.docking_0.weight.dtype
         rng = self._rng_state(dev)
-        cdf0, status = _prep if _prep is not None else self._prepare(B, dev, availabilities, selection_probabilities,
-                                                                     _device_dropout)
+        check = self.check_distribution if self.check_distribution is not None else (self.rng_mode == "host")
+        if _prep is None and self.rng_mode == "philox" and not check:
+            # device RNG, no host-side validity check wanted: the row thresholds are computed inside the forward launch
+            cdf0, status = self._select_inline(B, dev, availabilities, selection_probabilities, _device_dropout)
+        else:
+            cdf0, status = _prep if _prep is not None else self._prepare(B, dev, availabilities, selection_probabilities,
+                                                                         _device_dropout)
 
         u = None
         if self.rng_mode == "host":                               # replay of torch.multinomial's draws (:84)
             u = torch.rand(B * c, dtype=torch.float64, generator=self.generator).view(B, c).to(dev, non_blocking=True)
-        check = self.check_distribution if self.check_distribution is not None else (self.rng_mode == "host")
         if check and int(status.item()) & STATUS_INVALID_DISTRIBUTION:
             status.zero_()
             raise RuntimeError("invalid multinomial distribution (encountering probability entry < 0)")

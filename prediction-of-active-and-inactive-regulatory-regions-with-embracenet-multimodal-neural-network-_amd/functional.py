@@ -171,6 +171,22 @@ def select_prep(p, avail, B, rng=None, device_dropout=False, status=None):
     return cdf0, status
 
 
+class SelectInline:
+    """Handed to `embrace` in place of the cdf0 vector: selection probabilities [1|B, 2] fp32, availabilities [B, 2] fp32 or
+    None, the device-dropout switch and the sticky int32 status word -- the arguments of `select_prep`, evaluated inside the
+    forward launch instead (emb_embrace_fwd_select)."""
+    __slots__ = ("p", "avail", "device_dropout", "status")
+
+    def __init__(self, p, avail, device_dropout, status):
+        _lib.require_cuda(p, avail, status)
+        p = _as(p, torch.float32)
+        p = p.view(1, -1) if p.dim() == 1 else p
+        if p.shape[-1] != 2:
+            raise NotImplementedError("the HIP path implements the two-modality EmbraceNet (epigenomic + sequence)")
+        self.p, self.avail = p, (None if avail is None else _as(avail, torch.float32))
+        self.device_dropout, self.status = bool(device_dropout), status
+
+
 class _EmbraceFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x0, x1, w0, b0, w1, b1, cdf0, u, rng, compute_dtype):
@@ -188,9 +204,16 @@ class _EmbraceFn(torch.autograd.Function):
         if u is not None:
             u = _as(u, torch.float64)
             assert u.shape == (B, c)
-        check(_lib.lib().emb_embrace_fwd(ptr(x0c), ptr(x1c), ptr(w0c), ptr(b0c), ptr(w1c), ptr(b1c), ptr(cdf0), ptr(u),
-                                         rng.seed, rng.step_val, ptr(rng.step_dev), rng.row0, ptr(E), ptr(code),
-                                         B, d0, d1, c, DTYPE_CODE[T], stream()), "emb_embrace_fwd")
+        if isinstance(cdf0, SelectInline):                      # thresholds computed inside the launch (no emb_select_prep)
+            s_ = cdf0
+            check(_lib.lib().emb_embrace_fwd_select(ptr(x0c), ptr(x1c), ptr(w0c), ptr(b0c), ptr(w1c), ptr(b1c), ptr(s_.p),
+                                                    s_.p.shape[0], ptr(s_.avail), int(s_.device_dropout), ptr(s_.status), ptr(u),
+                                                    rng.seed, rng.step_val, ptr(rng.step_dev), rng.row0, ptr(E), ptr(code),
+                                                    B, d0, d1, c, DTYPE_CODE[T], stream()), "emb_embrace_fwd_select")
+        else:
+            check(_lib.lib().emb_embrace_fwd(ptr(x0c), ptr(x1c), ptr(w0c), ptr(b0c), ptr(w1c), ptr(b1c), ptr(cdf0), ptr(u),
+                                             rng.seed, rng.step_val, ptr(rng.step_dev), rng.row0, ptr(E), ptr(code),
+                                             B, d0, d1, c, DTYPE_CODE[T], stream()), "emb_embrace_fwd")
         ctx.save_for_backward(x0c, x1c, w0c, w1c, code)
         ctx.T = T
         ctx.in_dtypes = (x0.dtype, x1.dtype, w0.dtype, b0.dtype, w1.dtype, b1.dtype)
@@ -230,6 +253,7 @@ class _EmbraceFn(torch.autograd.Function):
 
 def embrace(x0, x1, w0, b0, w1, b1, cdf0, u=None, rng=None, compute_dtype=None):
     """Fused docking + ReLU + modality selection (EmbraceNetMultimodal.py:52-60, 80-88).
+    cdf0: the vector from `select_prep`, or a `SelectInline` (thresholds computed inside the launch).
     returns (E [B,c], code [B,c] uint8 with bit0 = selected modality)."""
     compute_dtype = compute_dtype or x0.dtype
     return _EmbraceFn.apply(x0, x1, w0, b0, w1, b1, cdf0, u, rng or RngState(), compute_dtype)

@@ -292,3 +292,32 @@ def test_random_points_of_the_search_space(ea, seed):
         assert np.isfinite(losses).all() and (losses > 0).all(), (precision, trial.asked, losses)
         assert counts[:, 3].tolist() == [B, B] and counts[:, 2].tolist() == [int(y.sum())] * 2
         assert not torch.equal(before, m.embracenet.docking_0.weight), (precision, trial.asked)
+
+
+@pytest.mark.parametrize("case", ["plain", "device_dropout", "availabilities"])
+def test_inline_selection_equals_the_prepared_cdf_path(ea, case):
+    """emb_embrace_fwd_select (row thresholds computed inside the forward launch) vs emb_select_prep + emb_embrace_fwd:
+    same code bytes (selected modality, ReLU bit) and the same fused output, bit for bit, over several RNG steps."""
+    F = ea.functional
+    B, d0, d1, c = 77, 16, 200, 96
+    g = torch.Generator(device="cpu").manual_seed(4)
+    x0, x1 = torch.rand(B, d0, generator=g).to(DEV), torch.rand(B, d1, generator=g).to(DEV)
+    w0, w1 = (torch.rand(c, d0, generator=g) - 0.5).to(DEV), ((torch.rand(c, d1, generator=g) - 0.5) * 0.2).to(DEV)
+    b0, b1 = torch.zeros(c, device=DEV), torch.zeros(c, device=DEV)
+    p = torch.tensor([[0.58, 0.42]], device=DEV)
+    avail = None
+    if case == "availabilities":
+        avail = torch.nn.functional.one_hot((torch.rand(B, generator=g) > 0.3).long(), 2).float().to(DEV)
+        avail[::5] = 1.0
+    for step in range(1, 5):
+        rng = F.RngState(seed=9, step_val=step, row0=1000)
+        cdf0, st = F.select_prep(p, avail, B, rng=rng, device_dropout=(case == "device_dropout"))
+        E_a, code_a = F.embrace(x0, x1, w0, b0, w1, b1, cdf0, rng=rng)
+        status = torch.zeros(1, dtype=torch.int32, device=DEV)
+        E_b, code_b = F.embrace(x0, x1, w0, b0, w1, b1, F.SelectInline(p, avail, case == "device_dropout", status), rng=rng)
+        assert torch.equal(code_a, code_b) and torch.equal(E_a, E_b), (case, step)
+        assert int(status) == int(st) == 0
+    bad = torch.tensor([[0.5, -0.5]], device=DEV)               # invalid distribution: the sticky status bit is raised
+    status = torch.zeros(1, dtype=torch.int32, device=DEV)
+    F.embrace(x0, x1, w0, b0, w1, b1, F.SelectInline(bad, None, False, status), rng=F.RngState(seed=1, step_val=1))
+    assert int(status) & ea.embracenet.STATUS_INVALID_DISTRIBUTION
