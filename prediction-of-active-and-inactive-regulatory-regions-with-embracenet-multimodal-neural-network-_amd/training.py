@@ -87,6 +87,7 @@ def fused_ticks(model, optimizer, device):
 
 GRAPH_STEPS = False          # default of StepRunner(graph=None): replay whole steps as hipGraphs (set_graph_steps)
 _GRAPH_WARMUP = 2            # eager steps of a batch shape before it is captured (allocations, optimizer state, packs)
+_GRAPH_LIMIT = 24            # graphs per StepRunner (shapes x hyper-parameter values); beyond that new keys run eagerly
 
 
 def set_graph_steps(enable):
@@ -136,10 +137,19 @@ class StepRunner:
         model, dev = self.model, self.device
         dt = getattr(model, "compute_dtype", None) or _input_dtype(model)
         dt2 = torch.uint8 if x_2.dtype == torch.uint8 else dt
-        key = (bool(training), bool(model.training), tuple(x_1.shape), tuple(x_2.shape), dt, dt2, next(model.parameters()).data_ptr())
+        # launch arguments frozen at capture: shapes, dtypes, the parameter storage and the optimizer's hyper-parameters
+        # (an lr scheduler therefore makes a new graph per value; after _GRAPH_LIMIT graphs the runner stops capturing)
+        hyper = tuple(tuple(sorted((k, v) for k, v in g_.items() if k != "params" and isinstance(v, (int, float, bool, tuple))))
+                      for g_ in self.optimizer.param_groups) if (training and self.optimizer is not None) else ()
+        key = (bool(training), bool(model.training), tuple(x_1.shape), tuple(x_2.shape), dt, dt2,
+               next(model.parameters()).data_ptr(), hyper)
         ent = self._graphs.get(key)
         if ent is None:
+            if len(self._graphs) >= _GRAPH_LIMIT:
+                return None
             ent = self._graphs[key] = {"seen": 0}
+        if ent.get("failed"):
+            return None
         if "g" not in ent:
             ent["seen"] += 1
             if ent["seen"] <= _GRAPH_WARMUP:
@@ -154,12 +164,21 @@ class StepRunner:
             st["y"] = static(target, torch.int64).reshape(-1)
             torch.cuda.synchronize()
             g = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g):
-                st["table"].n = 0
-                if training:
-                    st["out"], st["loss"] = self._train_step_eager(st["x1"], st["x2"], st["y"], st["table"], set_to_none=True)
-                else:
-                    st["out"], st["loss"] = self._eval_step_eager(st["x1"], st["x2"], st["y"], st["table"])
+            try:
+                with torch.cuda.graph(g):
+                    st["table"].n = 0
+                    if training:
+                        st["out"], st["loss"] = self._train_step_eager(st["x1"], st["x2"], st["y"], st["table"], set_to_none=True)
+                    else:
+                        st["out"], st["loss"] = self._eval_step_eager(st["x1"], st["x2"], st["y"], st["table"])
+            except Exception as e:                          # something in this configuration does not capture: stay eager
+                import warnings
+                warnings.warn(f"StepRunner: step capture failed ({type(e).__name__}: {e}); this batch shape runs eagerly")
+                F_.reduce_defer(False)
+                ent["failed"] = True
+                ent.pop("static", None)
+                torch.cuda.synchronize()
+                return None
             ent["g"] = g                                    # (capture does not execute: replay below runs this batch)
         st = ent["static"]
         for buf, t in ((st["x1"], x_1), (st["x2"], x_2), (st["y"], target)):
