@@ -179,6 +179,9 @@ class StepRunner:
                 ent.pop("static", None)
                 torch.cuda.synchronize()
                 return None
+            # keep only the values: holding the autograd graph of the captured step alive would pin its AccumulateGrad nodes
+            # to this capture's stream and make every later capture synchronise with it
+            st["out"], st["loss"] = st["out"].detach(), st["loss"].detach()
             ent["g"] = g                                    # (capture does not execute: replay below runs this batch)
         st = ent["static"]
         for buf, t in ((st["x1"], x_1), (st["x2"], x_2), (st["y"], target)):

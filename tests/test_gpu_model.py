@@ -321,3 +321,28 @@ def test_inline_selection_equals_the_prepared_cdf_path(ea, case):
     status = torch.zeros(1, dtype=torch.int32, device=DEV)
     F.embrace(x0, x1, w0, b0, w1, b1, F.SelectInline(bad, None, False, status), rng=F.RngState(seed=1, step_val=1))
     assert int(status) & ea.embracenet.STATUS_INVALID_DISTRIBUTION
+
+
+def test_graph_steps_follow_a_changing_learning_rate(ea):
+    """Launch arguments are frozen in a captured step, so the graphs are keyed on the optimizer's hyper-parameters: changing
+    lr mid-run (what an lr scheduler does) must give the parameters of the eager loop, bit for bit."""
+    from embracenet_amd import optim, training
+    def run(graph):
+        model, trial, hp, F_in = build(ea, "small", "lr", torch.float32)
+        model.set_rng("philox", seed=21)
+        model = training.prepare_model(model, DEV, "float32")
+        opt = optim.Adam(model.parameters(), lr=1e-3)
+        runner = training.StepRunner(model, opt, DEV, graph=graph)
+        table = ea.metrics.StepTable(32, DEV)
+        model.train()
+        for k in range(14):
+            if k in (5, 9):
+                for g_ in opt.param_groups:
+                    g_["lr"] *= 0.5
+            a, b, y = model_batch(f"lr/{k % 3}", 48, F_in, 0.3)
+            runner.train_step(torch.from_numpy(a).float(), torch.from_numpy(b).float(), torch.from_numpy(y), table)
+        return table.fetch()[0], {k: v.detach().cpu().clone() for k, v in model.state_dict().items()}, len(runner._graphs)
+    (la, sa, _), (lb, sb, n_graphs) = run(False), run(True)
+    assert n_graphs == 3 and np.array_equal(la, lb)
+    for k in sa:
+        assert torch.equal(sa[k], sb[k]), k
