@@ -298,6 +298,10 @@ def main():
     torch.cuda.synchronize()
 
     use_graph = not args.eager
+    if use_graph and args.sync_bn and dist_path and torch.distributed.get_backend() != "nccl":
+        use_graph = False                                 # the BatchNorm exchanges sit inside forward/backward: only RCCL
+        print("[bench] --sync-bn on a non-RCCL backend: collectives cannot be captured, running eager steps",   # captures
+              file=sys.stderr, flush=True)
     if use_graph:
         graph_mode = "one hipGraph per step"
         step = None
