@@ -42,6 +42,7 @@ def _run(world, rank, port, precision, out):
         a, b, y = model_batch(f"dpgpu/{k}", B, F_in, 0.3)
         runner.train_step(torch.from_numpy(a).to(cast), torch.from_numpy(b).to(cast), torch.from_numpy(y), table)   # the GLOBAL batch
     losses, counts = table.fetch()
+    np.save(out + f".idx{rank}.npy", model.embracenet.modality_indices().cpu().numpy())      # selection of the last step, local rows
     if world > 1:                                                # per-shard loss shares / counts -> global
         t = torch.from_numpy(np.concatenate([losses, counts.reshape(-1).astype(np.float64)]))
         torch.distributed.all_reduce(t)
@@ -68,6 +69,10 @@ def test_two_ranks_equal_one_process_on_the_global_batch(tmp_path, precision):
     tol = 1e-9 if precision == "float64" else 1e-4
     assert np.abs(a["losses"] - b["losses"]).max() < max(tol, 1e-6), (a["losses"], b["losses"])   # (the table stores fp32)
     assert np.array_equal(a["counts"][:, 2:], b["counts"][:, 2:])          # positives / rows of the global batch
+    # the sampled modality index of every (row, feature) does not depend on the sharding: bit-exact
+    idx1 = np.load(one + ".idx0.npy")
+    idx2 = np.concatenate([np.load(two + f".idx{r}.npy") for r in range(2)])
+    assert idx1.shape == (B, idx1.shape[1]) and np.array_equal(idx1, idx2)
     for k in a.files:
         if k in ("losses", "counts"):
             continue
