@@ -71,7 +71,8 @@ def test_g1_embracenet_forward_matches_reference(ea, i):
 
 # ------------------------------------------------------------------------- fwd/bwd vs numpy oracle
 SHAPES = [(8, 4, 64, 32), (64, 16, 1856, 512), (100, 32, 1024, 768), (37, 5, 70, 30), (256, 64, 2048, 256),
-          (1024, 16, 1856, 256), (3, 256, 96, 1024)]
+          (1024, 16, 1856, 256), (3, 256, 96, 1024),
+          (4096, 16, 1856, 256), (1024, 64, 1024, 1024)]      # full sizes of BASELINE configs 2, 5 (per GPU) and 4
 
 
 @pytest.mark.parametrize("dt", ["f64", "f32", "bf16"])
