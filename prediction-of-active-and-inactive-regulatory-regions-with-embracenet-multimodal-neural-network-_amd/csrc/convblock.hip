@@ -356,18 +356,22 @@ __global__ __launch_bounds__(256) void bn_bwd_dz_kernel(const T* __restrict__ do
     }
   }
   __syncthreads();   // LDS is reused for the block reduction
-  Acc* red = reinterpret_cast<Acc*>(smem);   // [TY][2][C]
+  // [TY][2C + 1]: the element-wise stores of a 32-lane group go to (ty, tx) = 8 x 4 rows/columns; with a pitch of 2C words
+  // (a multiple of the 32 store banks) all eight ty collided, the odd pitch spreads them over the banks (PMC: conflict
+  // cycles were 3/4 of this kernel's LDS cycles)
+  Acc* red = reinterpret_cast<Acc*>(smem);
+  const int RP = 2 * C + 1;
   if (ty < TY) {
 #pragma unroll
     for (int e = 0; e < VEC; ++e) {
-      red[((long)ty * 2 + 0) * C + c0 + e] = s1[e];
-      red[((long)ty * 2 + 1) * C + c0 + e] = s2[e];
+      red[(long)ty * RP + c0 + e] = s1[e];
+      red[(long)ty * RP + C + c0 + e] = s2[e];
     }
   }
   __syncthreads();
   for (int i = threadIdx.x; i < 2 * C; i += 256) {
     Acc a = 0;
-    for (int q = 0; q < TY; ++q) a += red[(long)q * 2 * C + i];
+    for (int q = 0; q < TY; ++q) a += red[(long)q * RP + i];
     bpart[(long)blockIdx.x * 2 * C + i] = a;
   }
 }
@@ -695,7 +699,7 @@ static int convblock_bwd(const void* dout, int dout_ncl, const uint8_t* argmax, 
     const int TY = 256 / (Cout / VEC);
     if (bn_phase != 2) {   // dz into the dy buffer + the per-block channel sums
       size_t sm = (size_t)(TT / 2 + 5) * Cout * (sizeof(T) + 1);
-      const size_t sm_red = (size_t)TY * 2 * Cout * sizeof(P);
+      const size_t sm_red = (size_t)TY * (2 * Cout + 1) * sizeof(P);
       if (sm_red > sm) sm = sm_red;
       sm = (sm + 15) & ~(size_t)15;
       if (dout_ncl)
