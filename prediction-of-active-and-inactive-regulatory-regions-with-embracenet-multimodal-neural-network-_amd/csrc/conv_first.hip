@@ -554,17 +554,21 @@ __global__ __launch_bounds__(256 * CH) void first_kernel(const FirstArgs a) {
   FIRST_T(40);
   if (MODE == F_BSUMS) {   // one partial row per workgroup: threads tid = c8 + CV*m share the channels 8*c8 .. 8*c8+7
     __syncthreads();
-    float* red2 = xt;                                  // [NTHR][16]
+    // [16][NTHR + 8]: value k (q1[0..7], q2[0..7]) of every thread in one row -- consecutive lanes store consecutive words,
+    // and the 16 * CV readers (k, c8) walk their row with lanes spread over the banks by the +8 pitch.  (The former
+    // [NTHR][16] layout put the 32 lanes of a store on two banks: 16-way conflicts, 16 stores per thread.)
+    float* red2 = xt;
+    constexpr int RP2 = NTHR + 8;
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
-      red2[threadIdx.x * 16 + e] = q1[e];
-      red2[threadIdx.x * 16 + 8 + e] = q2[e];
+      red2[e * RP2 + threadIdx.x] = q1[e];
+      red2[(8 + e) * RP2 + threadIdx.x] = q2[e];
     }
     __syncthreads();
-    if (threadIdx.x < 2 * BN) {
-      const int c = threadIdx.x % BN, which = threadIdx.x / BN, c8 = c >> 3, e = c & 7;
+    if (threadIdx.x < 16 * CV) {
+      const int k = threadIdx.x / CV, c8 = threadIdx.x % CV, which = k >> 3, c = c8 * 8 + (k & 7);
       float t = 0.0f;
-      for (int m = 0; m < NTHR / CV; ++m) t += red2[(c8 + CV * m) * 16 + which * 8 + e];
+      for (int m = 0; m < NTHR / CV; ++m) t += red2[k * RP2 + c8 + CV * m];
       if (c < C) a.partial[((long)bm * 2 + which) * C + c] = t;
     }
   }
