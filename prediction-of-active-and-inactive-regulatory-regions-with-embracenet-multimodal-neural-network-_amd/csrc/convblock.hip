@@ -308,10 +308,14 @@ __global__ __launch_bounds__(256) void bn_bwd_dz_kernel(const T* __restrict__ do
       else if (VEC == 4) *reinterpret_cast<uint32_t*>(asm_ + (long)i * VEC) = *reinterpret_cast<const uint32_t*>(argmax + nlc0 + (long)i * VEC);
       else *reinterpret_cast<uint16_t*>(asm_ + (long)i * VEC) = *reinterpret_cast<const uint16_t*>(argmax + nlc0 + (long)i * VEC);
     }
-    if (NCL_IN) {   // dout[b][c][p]: p contiguous
-      for (int i = threadIdx.x; i < NP * C; i += 256) {
-        const int c = i / NP, pp = i % NP;
-        dsm[(long)pp * C + c] = dout[((long)b * C + c) * Lp + P0 + pp];
+    if (NCL_IN) {   // dout[b][c][p], p contiguous: lanes walk p (coalesced loads), a thread gathers VEC channels of its p and
+      // stores them as ONE vector (element stores at a pitch of C elements put a whole store group on two banks)
+      for (int i = threadIdx.x; i < NP * TX; i += 256) {
+        const int cv = i / NP, pp = i % NP;
+        V v;
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) v[e] = dout[((long)b * C + cv * VEC + e) * Lp + P0 + pp];
+        *reinterpret_cast<V*>(dsm + (long)pp * C + cv * VEC) = v;
       }
     }
   }
