@@ -206,6 +206,10 @@ int emb_nadam_step_multi(void* const* params, const void* const* grads, void* co
  *                         uint8[B][L] with 0-3 = the hot channel of the one-hot column (dataprepare.py:398-412 order) and
  *                         any other value = an all-zero column; the one-hot row is formed in LDS, the [B][4][L] float
  *                         tensor and its layout conversion never exist (8x less input traffic).  x_codes = 0 otherwise.
+ *                         x_codes = 2 (emb_convblock_fwd, training, bf16, no bn_phase 2): x is the loader's [B][4][L] tensor
+ *                         itself; the statistics pass stages from it and writes the channels-last image [B][L][8] to `y`
+ *                         (here an OUTPUT the caller keeps for emb_convblock_bwd, which takes it as x with x_codes = 0) --
+ *                         the emb_ncl_to_nlc launch disappears from the training step.
  *   bn_phase / bn_sums    BatchNorm statistics of the GLOBAL batch when the batch rows are sharded over processes
  *                         (nn.BatchNorm1d at CNN_pre.py:41 normalises over the whole batch).  bn_phase = 0:
  *                         one call, statistics of this call's rows (bn_sums ignored).  Otherwise the block is two calls

@@ -9,7 +9,8 @@ int conv_first_supported(int dtype, int B, int L, int cin_pad, int Cout, int k);
 int conv_first_blocks(int B, int L, int cin_pad, int Cout, int k);                 // workgroups = partial rows = wgrad slices
 // x_codes == 0: x is [B][L][8] bf16 channels-last; else x is [B][L] uint8 base codes (0-3), one-hot expanded while staging.
 // each returns EMB_OK, a negative error, or 1 when the shapes do not qualify
-int conv_first_stats(const void* x, int x_codes, const void* w, const void* bias, void* partial, int* rows, int B, int L, int Cout, int k,
+// conv_first_stats: x_codes == 2 -> x is the loader's [B][4][L] bf16 tensor and nlc_out receives the [B][L][8] image.
+int conv_first_stats(const void* x, int x_codes, void* nlc_out, const void* w, const void* bias, void* partial, int* rows, int B, int L, int Cout, int k,
                      hipStream_t s);
 int conv_first_apply(const void* x, int x_codes, const void* w, const void* bias, const void* stats, void* out, uint8_t* argmax, int out_ncl,
                      float drop_p, uint64_t seed, uint64_t step_val, const uint64_t* step_dev, int64_t row0, int layer_id, int B, int L,

@@ -40,7 +40,10 @@ struct FirstArgs {
   const void* x;            // x_codes == 0: [B][L][8] bf16 channels-last, zero-padded channels
                             // x_codes != 0: [B][L] uint8 base codes (0-3 = A,C,G,T channel; anything else = all-zero column),
                             //               expanded to the one-hot row while staging
+                            // x_codes == 2 (F_STATS only): [B][4][L] bf16, the loader's layout; the statistics pass stages
+                            //               from it and writes the channels-last image to `nlc_out` for the later passes
   int x_codes;
+  __bf16* nlc_out;          // x_codes == 2: [B][L][8]
   const __bf16* w;          // [C][KK] packed weights, KK = k*8
   const float* bias;        // [C]
   const float* stats;       // [4][C] mean, invstd, scale, shift (not read by F_STATS)
@@ -100,7 +103,23 @@ __global__ __launch_bounds__(256 * CH) void first_kernel(const FirstArgs a) {
   bf16x8 xr[kFXV];
   auto issue_x = [&](int tm) {
     const int b0 = tm * SB;
-    if (!a.x_codes) {
+    if (MODE == F_STATS && a.x_codes == 2) {   // loader layout [b][ch][t]: four 2-byte loads per row, lanes walk t (coalesced)
+      const T* xb = reinterpret_cast<const T*>(a.x) + (long)b0 * 4 * L;
+#pragma unroll
+      for (int i = 0; i < kFXV; ++i) {
+        bf16x8 v;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = (T)0.0f;
+        if (x_pk[i] >= 0) {
+          const int s = x_pk[i] >> 16, tt = (x_pk[i] & 0xffff) - a.pad;
+          if (b0 + s < a.B && tt >= 0 && tt < L) {
+            const T* xp = xb + (long)s * 4 * L + tt;
+            v[0] = xp[0]; v[1] = xp[L]; v[2] = xp[2 * L]; v[3] = xp[3 * L];
+          }
+        }
+        xr[i] = v;
+      }
+    } else if (!a.x_codes) {
       const T* xb = reinterpret_cast<const T*>(a.x) + (long)b0 * L * XS;
 #pragma unroll
       for (int i = 0; i < kFXV; ++i) {
@@ -252,7 +271,10 @@ __global__ __launch_bounds__(256 * CH) void first_kernel(const FirstArgs a) {
     for (int i = 0; i < kFXV; ++i)
       if (x_pk[i] >= 0) {
         bf16x8 v = xr[i];
-        if (a.x_codes) {   // bf16 1.0 = 0x3F80 in the selected channel (two channels per 32-bit word)
+        if (MODE == F_STATS && a.x_codes == 2) {   // every real row is staged by exactly one tile: write the channels-last image
+          const int s = x_pk[i] >> 16, tt = (x_pk[i] & 0xffff) - a.pad;
+          if (b0 + s < a.B && tt >= 0 && tt < L) *reinterpret_cast<bf16x8*>(a.nlc_out + ((long)(b0 + s) * L + tt) * 8) = v;
+        } else if (a.x_codes) {   // bf16 1.0 = 0x3F80 in the selected channel (two channels per 32-bit word)
           const uint32_t code = __builtin_bit_cast(uint4, xr[i]).x;
           const uint4 w = make_uint4(code == 0 ? 0x00003F80u : code == 1 ? 0x3F800000u : 0u,
                                      code == 2 ? 0x00003F80u : code == 3 ? 0x3F800000u : 0u, 0u, 0u);
@@ -684,13 +706,13 @@ static void first_fill(FirstArgs& a, const FirstGeom& gm, int B, int L, int Cout
   a.SB = gm.SB; a.slot = gm.slot; a.tiles_m = gm.tiles_m; a.tpb = gm.tpb;
 }
 
-int conv_first_stats(const void* x, int x_codes, const void* w, const void* bias, void* partial, int* rows, int B, int L, int Cout,
+int conv_first_stats(const void* x, int x_codes, void* nlc_out, const void* w, const void* bias, void* partial, int* rows, int B, int L, int Cout,
                      int k, hipStream_t s) {
   FirstGeom gm;
   if (!first_geom(B, L, 8, Cout, k, &gm)) return 1;
   FirstArgs a{};
   first_fill(a, gm, B, L, Cout, k);
-  a.x = x; a.x_codes = x_codes; a.w = (const __bf16*)w; a.bias = (const float*)bias; a.partial = (float*)partial;
+  a.x = x; a.x_codes = x_codes; a.nlc_out = (__bf16*)nlc_out; a.w = (const __bf16*)w; a.bias = (const float*)bias; a.partial = (float*)partial;
   *rows = gm.nblk;
   return first_launch<F_STATS>(a, gm, s);
 }

@@ -599,14 +599,21 @@ static int convblock_fwd(const void* x, const void* wpack, const void* bias, con
   EMB_CHECK_ARG(cin_pad % VEC == 0 && Cout % VEC == 0, "emb_convblock_fwd: channels must be multiples of %d", VEC);
   const int R = B * L, KK = k * cin_pad, pad = (k - 1) / 2, Lp = (L - kPoolK) / kPoolS + 1;
   EMB_CHECK_ARG(Lp >= 1, "emb_convblock_fwd: sequence too short for the pooling window");
-  EMB_CHECK_ARG(!x_codes || y == nullptr, "emb_convblock_fwd: base-code input (x_codes) needs the fused first block (y == NULL)");
-  if (y == nullptr) {   // first block, nothing stored: statistics pass + fused apply pass, both recompute the convolution
+  EMB_CHECK_ARG(x_codes == 2 || !x_codes || y == nullptr, "emb_convblock_fwd: base-code input (x_codes = 1) needs the fused first block (y == NULL)");
+  EMB_CHECK_ARG(x_codes != 2 || (y != nullptr && training && bn_phase != 2 && cin_pad == 8 && sizeof(T) == 2),
+                "emb_convblock_fwd: x_codes = 2 (loader layout in, channels-last image out through y) is a training-mode bf16 call");
+  const void* x_img = x;   // what the passes after the statistics pass read
+  if (y == nullptr || x_codes == 2) {   // first block, nothing stored: statistics pass + fused apply pass, both recompute the convolution
     EMB_CHECK_ARG(conv_first_supported(dtype_code<T>(), B, L, cin_pad, Cout, k),
                   "emb_convblock_fwd: y may only be NULL when emb_convblock_needs_y() returns 0");
     int rows = 0;
     if (training && bn_phase != 2) {
-      const int rc0 = conv_first_stats(x, x_codes, wpack, bias, ws, &rows, B, L, Cout, k, s);
+      const int rc0 = conv_first_stats(x, x_codes, x_codes == 2 ? y : nullptr, wpack, bias, ws, &rows, B, L, Cout, k, s);
       if (rc0 != EMB_OK) return rc0 == 1 ? EMB_ERR_ARG : rc0;
+    }
+    if (x_codes == 2) {
+      x_img = y;
+      x_codes = 0;
     }
     if (bn_phase == 1) {
       bn_sums_kernel<P><<<Cout, 256, 0, s>>>((const P*)ws, rows, Cout, (double)R, bn_sums);
@@ -620,7 +627,7 @@ static int convblock_fwd(const void* x, const void* wpack, const void* bias, con
       bn_finalize_kernel<P, P><<<Cout, 256, 0, s>>>((const P*)ws, rows, Cout, (double)R, nullptr, (const P*)gamma, (const P*)beta,
                                                    (P*)rmean, (P*)rvar, training, momentum, eps, (P*)stats, (long long*)nbt);
     EMB_CHECK_LAUNCH();
-    const int rc1 = conv_first_apply(x, x_codes, wpack, bias, stats, out, argmax, out_ncl, drop_p, seed, step_val, step_dev, row0, layer_id, B, L,
+    const int rc1 = conv_first_apply(x_img, x_codes, wpack, bias, stats, out, argmax, out_ncl, drop_p, seed, step_val, step_dev, row0, layer_id, B, L,
                                      Cout, k, s);
     return rc1 == 1 ? EMB_ERR_ARG : rc1;
   }

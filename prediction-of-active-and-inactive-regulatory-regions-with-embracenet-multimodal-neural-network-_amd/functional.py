@@ -597,7 +597,15 @@ class _ConvStackFn(torch.autograd.Function):
                 cur[:, :, :4] = (x.unsqueeze(-1) == torch.arange(4, device=dev, dtype=torch.uint8)).to(T)
         else:
             cur = torch.empty(B, L, cin_pad, dtype=T, device=dev)
-            check(L_.emb_ncl_to_nlc(ptr(x), DTYPE_CODE[x.dtype], ptr(cur), code, B, C0, L, cin_pad, stream()), "emb_ncl_to_nlc")
+            Cout0, _, k0 = tensors[0].shape
+            # training step on the loader's [B, 4, L] windows in the compute dtype: the first block's statistics pass stages
+            # straight from that layout and writes the channels-last image itself (x_codes = 2) -- no conversion launch
+            ncl_direct = (training and bn_sync is None and T == torch.bfloat16 and x.dtype == T and C0 == 4 and cin_pad == 8
+                          and L_.emb_convblock_needs_y(B, L, cin_pad, Cout0, k0, code) == 0)
+            if ncl_direct:
+                x_codes = 2
+            else:
+                check(L_.emb_ncl_to_nlc(ptr(x), DTYPE_CODE[x.dtype], ptr(cur), code, B, C0, L, cin_pad, stream()), "emb_ncl_to_nlc")
         saved, shapes = [], []
         n_layers = len(meta)
         for i, m in enumerate(meta):
@@ -621,9 +629,12 @@ class _ConvStackFn(torch.autograd.Function):
             sync = bn_sync if training else None
             sums = torch.empty(2 * Cout + 1, dtype=torch.float64, device=dev) if sync is not None else None
             for phase in ((1, 2) if sync is not None else (0,)):
-                check(L_.emb_convblock_fwd(ptr(cur), ptr(wpack), ptr(b.detach()), ptr(g.detach()), ptr(beta.detach()), ptr(rmean),
+                ncl_in = i == 0 and x_codes == 2                # loader layout in, channels-last image out through `y`
+                check(L_.emb_convblock_fwd(ptr(x if ncl_in else cur), ptr(wpack), ptr(b.detach()), ptr(g.detach()),
+                                           ptr(beta.detach()), ptr(rmean),
                                            ptr(rvar), int(training), float(m["momentum"]), float(m["eps"]), float(m["drop_p"]),
-                                           rng.seed, rng.step_val, ptr(rng.step_dev), rng.row0, int(m["layer_id"]), ptr(y),
+                                           rng.seed, rng.step_val, ptr(rng.step_dev), rng.row0, int(m["layer_id"]),
+                                           ptr(cur) if ncl_in else ptr(y),
                                            ptr(stats), ptr(out), ptr(argmax), int(last), ptr(ws), ws.numel(), ptr(nbt),
                                            x_codes if i == 0 else 0, phase, ptr(sums), B, L, cin_pad, Cout, k, code, stream()),
                       "emb_convblock_fwd")
@@ -633,7 +644,7 @@ class _ConvStackFn(torch.autograd.Function):
             shapes.append((L, Cin, cin_pad, Cout, k, float(m["drop_p"]), fused))
             cur, L, cin_pad = out, Lp, Cout
         ctx.save_for_backward(*saved)
-        ctx.cfg = (T, int(training), B, shapes, x_codes, bn_sync if training else None)
+        ctx.cfg = (T, int(training), B, shapes, 0 if x_codes == 2 else x_codes, bn_sync if training else None)   # (backward reads the saved channels-last image)
         ctx.sinks = tuple(grad_sink(tensors[6 * i + j], P) for i in range(n_layers) for j in range(4))
         return cur.reshape(B, -1)
 

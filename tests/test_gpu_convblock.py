@@ -268,3 +268,27 @@ def test_global_batch_batchnorm_over_two_shards_equals_one_process(ea, name, B, 
             assert (rk[i].bn.running_mean.double() - fb.bn.running_mean.double()).abs().max() < max(tol, 1e-6)
             assert (rk[i].bn.running_var.double() - fb.bn.running_var.double()).abs().max() < max(tol, 1e-6)
             assert int(rk[i].bn.num_batches_tracked) == 1
+
+
+@pytest.mark.parametrize("spec,L", [([(4, 64, 15), (64, 32, 15)], 256), ([(4, 16, 5)], 256), ([(4, 32, 11), (32, 32, 5)], 100)],
+                         ids=["a549", "one", "short100"])
+def test_loader_layout_staged_by_the_statistics_pass_equals_the_conversion_launch(ea, spec, L):
+    """Training step on [B, 4, L] windows already in the compute dtype: the first block's statistics pass reads the loader's
+    layout itself and writes the channels-last image (x_codes = 2) -- outputs, gradients and BatchNorm statistics must be
+    bit-identical to the path through emb_ncl_to_nlc (taken here by handing the same values over in fp32)."""
+    F = ea.functional
+    B = 21
+    x = torch.from_numpy(np.ascontiguousarray(dg.onehot_sequence("ncl2/x", B)[:, :, :L])).to(DEV)
+    res = []
+    for dtype_in in (torch.bfloat16, torch.float32):
+        blocks = [Blk(f"ncl2/{i}", ci, co, k, torch.float32) for i, (ci, co, k) in enumerate(spec)]
+        for b in blocks:
+            b.conv.to(DEV); b.bn.to(DEV)
+        layers = [dict(conv=b.conv, bn=b.bn, drop_p=0.2 if i == 0 else 0.0, layer_id=4 + i) for i, b in enumerate(blocks)]
+        out = F.conv_stack(x.to(dtype_in), layers, True, rng=F.RngState(seed=5, step_val=2), compute_dtype=torch.bfloat16)
+        out.backward(torch.ones_like(out) * 0.01)
+        res.append((out.detach(), [p.grad.clone() for b in blocks for p in b.params()],
+                    [b.bn.running_var.clone() for b in blocks]))
+    assert torch.equal(res[0][0], res[1][0])
+    for a, b in zip(res[0][1] + res[0][2], res[1][1] + res[1][2]):
+        assert torch.equal(a, b)
