@@ -142,6 +142,27 @@ static int launch_conv_gemm(const void* x, const void* w, const void* bias, void
   return EMB_OK;
 }
 
+// sum of (a, b) over the 256 threads of a finalize workgroup, result in sa[0] / sb[0]: butterfly inside each wave (no
+// barrier), the four wave sums meet in LDS in wave order -- one barrier instead of the eight of a shared-memory tree
+__device__ __forceinline__ void block256_sum2(double a, double b, double* sa, double* sb) {
+#pragma unroll
+  for (int m = 32; m >= 1; m >>= 1) {
+    a += __shfl_xor(a, m, 64);
+    b += __shfl_xor(b, m, 64);
+  }
+  const int tid = threadIdx.x;
+  if ((tid & 63) == 0) {
+    sa[1 + (tid >> 6)] = a;
+    sb[1 + (tid >> 6)] = b;
+  }
+  __syncthreads();
+  if (tid == 0) {
+    sa[0] = ((sa[1] + sa[2]) + sa[3]) + sa[4];
+    sb[0] = ((sb[1] + sb[2]) + sb[3]) + sb[4];
+  }
+  __syncthreads();
+}
+
 // ------------------------------------------------------------------------------- BN statistics
 // stats[0..3][C] = mean, invstd, scale = gamma*invstd, shift = beta - mean*scale   (P-typed)
 // `count_dev` (global-batch statistics, emb_convblock_fwd bn_phase 2): the row count behind the sums, on the device.
@@ -163,16 +184,7 @@ __global__ __launch_bounds__(256) void bn_finalize_kernel(const PP* __restrict__
       a += (double)partial[((long)t * 2 + 0) * C + c];
       b += (double)partial[((long)t * 2 + 1) * C + c];
     }
-    sa[tid] = a;
-    sb[tid] = b;
-    __syncthreads();
-    for (int s = 128; s > 0; s >>= 1) {
-      if (tid < s) {
-        sa[tid] += sa[tid + s];
-        sb[tid] += sb[tid + s];
-      }
-      __syncthreads();
-    }
+    block256_sum2(a, b, sa, sb);
     mean = sa[0] / count;
     var = sb[0] / count - mean * mean;   // biased variance (normalisation); double keeps the cancellation benign
     if (var < 0) var = 0;
@@ -397,16 +409,7 @@ __global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(const PP* __restri
     a += (double)bpart[((long)t * 2 + 0) * C + c];
     b += (double)bpart[((long)t * 2 + 1) * C + c];
   }
-  sa[tid] = a;
-  sb[tid] = b;
-  __syncthreads();
-  for (int s = 128; s > 0; s >>= 1) {
-    if (tid < s) {
-      sa[tid] += sa[tid + s];
-      sb[tid] += sb[tid + s];
-    }
-    __syncthreads();
-  }
+  block256_sum2(a, b, sa, sb);
   if (tid == 0) {
     if (dbeta != nullptr) {
       dbeta[c] = (P)sa[0];
@@ -436,16 +439,7 @@ __global__ __launch_bounds__(256) void bn_sums_kernel(const P* __restrict__ part
     a += (double)partial[((long)t * 2 + 0) * C + c];
     b += (double)partial[((long)t * 2 + 1) * C + c];
   }
-  sa[tid] = a;
-  sb[tid] = b;
-  __syncthreads();
-  for (int s = 128; s > 0; s >>= 1) {
-    if (tid < s) {
-      sa[tid] += sa[tid + s];
-      sb[tid] += sb[tid + s];
-    }
-    __syncthreads();
-  }
+  block256_sum2(a, b, sa, sb);
   if (tid == 0) {
     sums[c] = sa[0];
     sums[C + c] = sb[0];
