@@ -47,10 +47,21 @@ WORKLOADS["cfg4"] = dict(name="K562 E-vs-P, c=1024, d1=1024, n_post=2, fp32, B=1
                                  EMBRACENET_dropout_l0=0.0, EMBRACENET_n_units_l1=128, EMBRACENET_dropout_l1=0.0,
                                  selection_probabilities_FFNN=0.5))
 
-# BASELINE.json configs[4]: modality dropout p = 0.5 is the model's own training behaviour (EmbraceNetMultimodal.py:178-182),
-# batch 4096, hipGraph-captured step; per-GPU shard of the 8-GPU job = the same model at B = 4096 / N (here: the 1-GPU case)
-WORKLOADS["cfg5"] = dict(WORKLOADS["cfg2"], name="GM12878-like 2-modality EmbraceNet with modality dropout, c=256, B=4096/GPU, bf16",
-                         B=4096)
+# BASELINE.json configs[2] as SURVEY 8d defines it ("7 cell lines concatenated": F = 562 = the widest line, the nets of cfg1
+# with c = 768, fp32, global batch 8192 -> 1024 rows per GPU)
+WORKLOADS["cfg3"] = dict(name="7 cell lines (F=562), 2-modality EmbraceNet, c=768, B=1024/GPU, fp32", F=562, B=1024,
+                         dtype="float32", pos=0.1, hp=dict(WORKLOADS["cfg2"]["hp"], EMBRACENET_embracement_size=768))
+# BASELINE.json configs[4] as SURVEY 8d defines it: GM12878 (F = 152), c = 768, d0 = 32, d1 = 3712, modality dropout (the
+# model's own training behaviour, EmbraceNetMultimodal.py:178-182), global batch 4096 -> 512 rows per GPU, graph-captured step
+WORKLOADS["cfg5"] = dict(name="GM12878 (F=152) 2-modality EmbraceNet with modality dropout, c=768, d0=32, d1=3712, B=512/GPU, bf16",
+                         F=152, B=512, dtype="bfloat16", pos=0.183,
+                         hp=dict(FFNN_n_layers=2, FFNN_n_units_l0=64, FFNN_dropout_l0=0.0, FFNN_n_units_l1=32, FFNN_dropout_l1=0.0,
+                                 CNN_n_layers=2, CNN_out_channels_l0=64, CNN_kernel_size_l0=11, CNN_dropout_l0=0,
+                                 CNN_out_channels_l1=64, CNN_kernel_size_l1=11, CNN_dropout_l1=0,
+                                 EMBRACENET_embracement_size=768, n_post_layers=0, selection_probabilities_FFNN=0.5))
+# the cfg2 network at a 4x larger per-GPU batch (what a single GPU does with the whole 4096-row global batch of configs[4])
+WORKLOADS["cfg2_b4096"] = dict(WORKLOADS["cfg2"], name="A549 2-modality EmbraceNet, c=256, B=4096/GPU, bf16 (cfg2 network, 4x batch)",
+                               B=4096)
 
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s (spec); ~6.3 TB/s achievable
 MFMA_PEAK_TFLOPS = {"bfloat16": 2500.0, "float32": 157.3, "float64": 78.6}

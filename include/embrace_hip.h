@@ -23,7 +23,8 @@
  * RNG contract (perf mode; parity mode injects the host generator's uniforms instead):
  *  Philox4x32-10, key = seed, counter = (index.lo, index.hi, stream.lo, stream.hi) with
  *  stream = (step << 8) | kind and step = step_val + (step_dev ? *step_dev : 0).
- *  kinds: 0 selection uniform of element (global_row * c + j) -> 53-bit double from words 0,1;
+ *  kinds: 0 selection uniform of element e = global_row * c + j -> word (e & 3) of the counter e >> 2, u = word * 2^-32
+ *           (one Philox call per four consecutive elements; idx = cdf0 < u  <=>  floor(cdf0 * 2^32) < word);
  *         1 modality-dropout gate (index 0) -> 24-bit float from word 0;
  *         2 per-row dropped-modality draw (index global_row) -> 24-bit float from word 0;
  *         16+L activation-dropout mask of layer L (index global_row * N + j) -> 24-bit float.
@@ -43,8 +44,9 @@ extern "C" {
 enum { EMB_F32 = 0, EMB_BF16 = 1, EMB_F64 = 2 };
 enum { EMB_OK = 0, EMB_ERR_ARG = -1, EMB_ERR_DTYPE = -2, EMB_ERR_ALIGN = -3, EMB_ERR_LAUNCH = -4 };
 enum { EMB_RNG_SELECT = 0, EMB_RNG_GATE = 1, EMB_RNG_ROWMOD = 2, EMB_RNG_DROPOUT0 = 16 };
-/* bits of the per-element code byte written by emb_embrace_fwd */
-enum { EMB_CODE_IDX = 1, EMB_CODE_ACTIVE = 2 };
+/* bits of the per-element code byte written by emb_embrace_fwd: the selected modality, whether its ReLU was active, and
+ * (derived, for the backward kernel's fragment masks) "gradient flows to docking_0 / docking_1 here" = ACTIVE && IDX == 0 / 1 */
+enum { EMB_CODE_IDX = 1, EMB_CODE_ACTIVE = 2, EMB_CODE_KEEP0 = 64, EMB_CODE_KEEP1 = 128 };
 /* bits of the status word */
 enum { EMB_STATUS_INVALID_DISTRIBUTION = 1 };
 

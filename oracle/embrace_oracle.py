@@ -243,6 +243,17 @@ def philox_uniform53(seed, stream, index):
     return uniform53(raw)
 
 
+def philox_select_uniform(seed, stream, element):
+    """Perf-mode selection uniform of element e = global_row * c + j (RNG kind 0, include/embrace_hip.h): word (e & 3) of
+    Philox(counter = e >> 2) times 2^-32 -- one Philox call serves four consecutive elements.  Exact in fp64, so
+    embrace_indices(cdf, u) on it is the kernels' integer compare floor(cdf0 * 2^32) < word."""
+    e = np.asarray(element, dtype=np.uint64)
+    w = philox_words(seed, stream, e >> np.uint64(2))
+    k = (e & np.uint64(3)).astype(np.int64)
+    word = np.take_along_axis(w, k[..., None], axis=-1)[..., 0]
+    return word.astype(F64) * (2.0 ** -32)
+
+
 def philox_uniform24(seed, stream, index):
     """fp32 uniform with the same construction as at::uniform_real_distribution<float>:
     (x & (2^24 - 1)) * 2^-24."""

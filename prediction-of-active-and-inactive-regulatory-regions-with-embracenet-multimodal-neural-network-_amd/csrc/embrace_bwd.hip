@@ -12,6 +12,9 @@
 // byte-granular scalar base, which s_load does not honour: the loaded pointers were garbage.)
 #include "gemm_tile.h"
 #include "reduce.h"
+#include "embrace_bwd_split.h"
+#include <cstdlib>
+#include <cstring>
 
 namespace emb {
 
@@ -183,6 +186,14 @@ extern "C" int emb_embrace_bwd(const void* dE, const uint8_t* code, const void* 
   EMB_CHECK_ARG(dE && code && X0 && X1 && W0 && W1 && dW0 && db0 && dW1 && db1, "emb_embrace_bwd: null pointer");
   EMB_CHECK_ARG(B > 0 && d0 > 0 && d1 > 0 && c > 0, "emb_embrace_bwd: bad dims B=%d d0=%d d1=%d c=%d", B, d0, d1, c);
   hipStream_t s = (hipStream_t)stream;
+  if (dtype == EMB_BF16) {   // K split over waves, LDS-DMA rings (embrace_bwd_split.h); EMB_BWD_IMPL=tiled keeps the round-1 kernel
+    static const bool use_split = [] { const char* e = getenv("EMB_BWD_IMPL"); return !(e && strcmp(e, "tiled") == 0); }();
+    static const int force_S = [] { const char* e = getenv("EMB_BWD_S"); return e ? atoi(e) : 0; }();
+    if (use_split) {
+      const int rc = emb::bwd_split_dispatch(dE, code, X0, X1, W0, W1, dX0, dX1, dW0, db0, dW1, db1, workspace, workspace_bytes, B, d0, d1, c, force_S, s);
+      if (rc != 1) return rc;
+    }
+  }
   switch (dtype) {
     case EMB_F32: return emb::bwd_dispatch<float>(dE, code, X0, X1, W0, W1, dX0, dX1, dW0, db0, dW1, db1, workspace, workspace_bytes, B, d0, d1, c, s);
     case EMB_BF16: return emb::bwd_dispatch<__bf16>(dE, code, X0, X1, W0, W1, dX0, dX1, dW0, db0, dW1, db1, workspace, workspace_bytes, B, d0, d1, c, s);

@@ -44,6 +44,30 @@ __device__ __forceinline__ float select_cdf(const SelArgs& s, int row, uint64_t 
   return *ok ? cdf : __builtin_nanf("");
 }
 
+// Perf-mode selection uniforms (RNG kind 0): element e = global_row * c + j takes word (e & 3) of Philox(counter = e >> 2),
+// u = word * 2^-32.  One Philox call serves four consecutive elements (it was one call per element, 20 64-bit multiplies
+// each: the dominant cost of the epilogue); (double)cdf0 < u is evaluated exactly as the integer compare T < word with
+// T = floor(cdf0 * 2^32) (select_threshold32).
+__device__ __forceinline__ uint32_t philox_word(const Philox4& p, unsigned k) {
+  return k == 0 ? p.x : (k == 1 ? p.y : (k == 2 ? p.z : p.w));
+}
+__device__ __forceinline__ void select_words4(uint64_t seed, uint64_t stream, uint64_t e0, uint32_t (&w)[4]) {
+  const Philox4 p0 = philox4x32_10(seed, stream, e0 >> 2);
+  const unsigned k0 = (unsigned)(e0 & 3);
+  if (k0 == 0) {
+    w[0] = p0.x; w[1] = p0.y; w[2] = p0.z; w[3] = p0.w;
+  } else {            // four elements straddle two counters (c not a multiple of 4)
+    const Philox4 p1 = philox4x32_10(seed, stream, (e0 >> 2) + 1);
+#pragma unroll
+    for (unsigned j = 0; j < 4; ++j) w[j] = (k0 + j < 4) ? philox_word(p0, k0 + j) : philox_word(p1, k0 + j - 4);
+  }
+}
+__device__ __forceinline__ uint64_t select_threshold32(float cdf0) {
+  if (!(cdf0 == cdf0)) return 1ull << 32;       // invalid row: "thr < u" is false for every u
+  const double t = (double)cdf0 * 4294967296.0;
+  return t >= 4294967296.0 ? (1ull << 32) : (t <= 0.0 ? 0ull : (uint64_t)t);
+}
+
 template <class Cfg>
 __device__ __forceinline__ void embrace_epilogue(const typename Cfg::M::Acc* cs0, const typename Cfg::M::Acc* cs1,
                                                  const typename Cfg::M::Acc* __restrict__ b0,
@@ -82,11 +106,10 @@ __device__ __forceinline__ void embrace_epilogue(const typename Cfg::M::Acc* cs0
         for (int j = 0; j < 4; ++j) uu[j] = j < nval ? u[base + j] : 0.0;
       }
     } else {
+      uint32_t w4[4];
+      select_words4(seed, stream, (uint64_t)(grow0 + row) * (uint64_t)c + (uint64_t)col, w4);
 #pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        const Philox4 ph = philox4x32_10(seed, stream, (uint64_t)(grow0 + row) * (uint64_t)c + (uint64_t)(col + j));
-        uu[j] = uniform53(ph.x, ph.y);
-      }
+      for (int j = 0; j < 4; ++j) uu[j] = (double)w4[j] * (1.0 / 4294967296.0);   // exact: thr < uu  <=>  floor(thr * 2^32) < word
     }
     T ev[4];
     uint8_t cv[4];
@@ -97,7 +120,7 @@ __device__ __forceinline__ void embrace_epilogue(const typename Cfg::M::Acc* cs0
       const Acc pre = sel1 ? cs1[r * Cfg::CS + cq + j] + b1[cc] : cs0[r * Cfg::CS + cq + j] + b0[cc];
       const bool act = pre > (Acc)0;
       ev[j] = (T)(act ? pre : (Acc)0);
-      cv[j] = (uint8_t)((sel1 ? EMB_CODE_IDX : 0) | (act ? EMB_CODE_ACTIVE : 0));
+      cv[j] = (uint8_t)((sel1 ? EMB_CODE_IDX : 0) | (act ? (EMB_CODE_ACTIVE | (sel1 ? EMB_CODE_KEEP1 : EMB_CODE_KEEP0)) : 0));
     }
     if (nval == 4 && vec_c) {
       typedef T TV4 __attribute__((ext_vector_type(4)));

@@ -8,6 +8,9 @@
 // index), pre = acc_idx + b_idx[col], E = max(pre, 0), code = idx | (pre > 0) << 1.
 #include "embrace_epilogue.h"
 #include "embrace_stream.h"
+#include "embrace_split.h"
+#include <cstdlib>
+#include <cstring>
 
 namespace emb {
 
@@ -112,6 +115,12 @@ template <typename T> static int fwd_dispatch(const void* X0, const void* X1, co
                                               const void* b1, const SelArgs& sel, const double* u, uint64_t seed,
                                               uint64_t step_val, const uint64_t* step_dev, int64_t row0, void* E,
                                               uint8_t* code, int B, int d0, int d1, int c, hipStream_t s) {
+  // EMB_FWD_IMPL=tiled keeps the round-1 kernels (A/B runs); default: K split over waves with LDS-DMA rings
+  static const bool use_split = [] { const char* e = getenv("EMB_FWD_IMPL"); return !(e && strcmp(e, "tiled") == 0); }();
+  if (use_split) {
+    const int rc = fwd_split_dispatch<T>(X0, X1, W0, b0, W1, b1, sel, u, seed, step_val, step_dev, row0, E, code, B, d0, d1, c, s);
+    if (rc != 1) return rc;
+  }
   const long tiles_L = (long)cdiv(B, 64) * cdiv(c, 64);
   if (tiles_L < 192) {   // small B*c, long K: operands streamed straight into MFMA fragments, K split over the 4 waves
     const int rc = launch_embrace_fwd_stream<T>(X0, X1, W0, b0, W1, b1, sel, u, seed, step_val, step_dev, row0, E, code, B, d0, d1, c, s);

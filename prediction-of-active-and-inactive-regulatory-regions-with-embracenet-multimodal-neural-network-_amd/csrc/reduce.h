@@ -15,7 +15,7 @@ struct ReduceJob {
   void* out[8];      // RJ_LINEAR: dW, db;  RJ_CONV: dW, dbias;  RJ_MLP: dW_0..3, db_0..3;  RJ_HEAD_STATS: loss (float), confusion (int64[4])
   long per;
   int S, kind;
-  int iv[9];         // RJ_LINEAR: N (row = [N values | bias]);  RJ_CONV: Cin, cin_pad, k;  RJ_MLP: L, N_0..3, K_0..3
+  int iv[9];         // RJ_LINEAR: N, pitch (row = [N values | bias | pad], pitch 0 = N + 1);  RJ_CONV: Cin, cin_pad, k;  RJ_MLP: L, N_0..3, K_0..3
 };
 
 // immediate mode: launches on `s`; deferred mode: queued until emb_reduce_flush().  is_double selects P.

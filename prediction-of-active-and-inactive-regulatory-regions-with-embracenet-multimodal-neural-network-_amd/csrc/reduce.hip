@@ -18,11 +18,11 @@ struct ReduceTable {
 
 template <typename P> __device__ __forceinline__ void reduce_write(const ReduceJob& j, long q, P t) {
   if (j.kind == RJ_LINEAR) {
-    const int N = j.iv[0];
-    const long m = q / (N + 1);
-    const int n = (int)(q - m * (N + 1));
+    const int N = j.iv[0], pitch = j.iv[1] > 0 ? j.iv[1] : N + 1;   // slab row = [N values | bias | padding up to pitch]
+    const long m = q / pitch;
+    const int n = (int)(q - m * pitch);
     if (n == N) ((P*)j.out[1])[m] = t;
-    else ((P*)j.out[0])[m * N + n] = t;
+    else if (n < N) ((P*)j.out[0])[m * N + n] = t;
   } else if (j.kind == RJ_CONV) {   // slab row = [k*cin_pad tap-major columns | bias]; dW in torch layout [Cout][Cin][k]
     const int Cin = j.iv[0], cin_pad = j.iv[1], k = j.iv[2], KK = k * cin_pad;
     const int o = (int)(q / (KK + 1)), col = (int)(q - (long)o * (KK + 1));

@@ -1,0 +1,180 @@
+// Building blocks of the "K split over waves" kernels (embrace_split.h: fused forward; embrace_bwd2.hip: backward).
+//
+// Shape of these kernels: a workgroup owns one output tile; its 4 waves split the REDUCTION range in 128-byte-wide
+// chunks (wave w takes chunks w, w+4, ...), every wave streams its own chunks global -> LDS by LDS-DMA
+// (global_load_lds_dwordx4: no VGPRs, whole 128-byte lines, up to NSTAGE chunks in flight per wave) into a private
+// ring, reads MFMA fragments back and accumulates a full partial tile.  There is NO workgroup barrier in the main loop
+// (a wave's LDS-DMA data is ordered for its own reads by its own counted vmcnt); the four partial tiles meet in LDS once.
+//
+// Chunk image: ROWS rows x 128 bytes, the eight 16-byte slots of a row XOR-permuted by swz16(row).  The permutation is
+// applied on the per-lane SOURCE address (the LDS-DMA destination is lane-linear) and again in the fragment reads.
+// With swz16 both kinds of fragment read are bank-conflict free: ds_read_b128 of a row-major operand (rows = tile rows,
+// bytes = k) and ds_read_b64_tr_b16 of a K-major operand (rows = k, bytes = tile columns).
+#pragma once
+#include "gemm_core.h"
+
+namespace emb {
+
+typedef __attribute__((address_space(3))) void lds_void_t;
+typedef __attribute__((address_space(1))) const void gbl_cvoid_t;
+
+__device__ __forceinline__ int swz16(int row) { return (((row >> 1) & 1) << 1) | (((row >> 3) & 1) << 2); }
+
+// 16 zero bytes: what an LDS-DMA lane outside the matrix reads
+__device__ __attribute__((aligned(16))) const unsigned int g_zero16[4] = {0u, 0u, 0u, 0u};
+
+// Issue the LDS-DMA of one chunk image: rows row0 .. row0+ROWS-1 (rows >= nrows read zeros) of a row-major matrix with
+// `ld_bytes` per row, bytes [colb0, colb0+128) of each row (bytes >= rowbytes read zeros; rowbytes % 16 == 0).
+// ROWS/8 wave-instructions of 1 KiB.  `lds` = wave-uniform LDS byte address of the image.
+template <int ROWS>
+__device__ __forceinline__ void dma_chunk(const char* __restrict__ g, long ld_bytes, int row0, int nrows, int colb0,
+                                          int rowbytes, uint32_t lds, int lane) {
+  const int rl = lane >> 3, ps = lane & 7;
+#pragma unroll
+  for (int j = 0; j < ROWS / 8; ++j) {
+    const int row = 8 * j + rl;
+    const int cb = colb0 + 16 * (ps ^ swz16(row));
+    const bool ok = (row0 + row < nrows) && (cb < rowbytes);
+    const char* src = ok ? g + (long)(row0 + row) * ld_bytes + cb : reinterpret_cast<const char*>(g_zero16);
+    __builtin_amdgcn_global_load_lds((gbl_cvoid_t*)src, (lds_void_t*)(uintptr_t)(lds + j * 1024), 16, 0, 0);
+  }
+}
+
+// per-lane byte offsets of the two fragment reads (k bytes [0,64) and [64,128) of the chunk) of a ROW-MAJOR operand
+// inside a 16-row tile: lane (r = lane & 15, g = lane >> 4) reads slot 4h + g of row r
+struct RmLane {
+  uint32_t off[2];
+};
+__device__ __forceinline__ RmLane rm_lane(int lane) {
+  const int r = lane & 15, g = lane >> 4, s = swz16(r);
+  return RmLane{{(uint32_t)(r * 128 + ((g ^ s) << 4)), (uint32_t)(r * 128 + (((4 + g) ^ s) << 4))}};
+}
+template <typename T> __device__ __forceinline__ typename Vec16<T>::type lds_read16(uint32_t addr) {
+  using V = typename Vec16<T>::type;
+  typedef __attribute__((address_space(3))) V lds_V;
+  return *(const lds_V*)(uintptr_t)addr;
+}
+
+// one 16-byte fragment = STEPS MFMA steps (bf16: one 16x16x32; f32: four 16x16x4; f64: two 16x16x4); for f32 / f64 the
+// k values are visited in a permuted order that is the same for both operands
+template <typename T> struct FragSteps;
+template <> struct FragSteps<__bf16> {
+  static constexpr int STEPS = 1;
+  __device__ static bf16x8 get(const bf16x8& v, int) { return v; }
+};
+template <> struct FragSteps<float> {
+  static constexpr int STEPS = 4;
+  __device__ static float get(const f32x4& v, int j) { return v[j]; }
+};
+template <> struct FragSteps<double> {
+  static constexpr int STEPS = 2;
+  __device__ static double get(const f64x2& v, int j) { return v[j]; }
+};
+
+template <typename T, int MI, int NI>
+__device__ __forceinline__ void mma_frags(const typename Vec16<T>::type (&a)[MI], const typename Vec16<T>::type (&b)[NI],
+                                          typename Mma<T>::AccV (&acc)[MI][NI]) {
+#pragma unroll
+  for (int st = 0; st < FragSteps<T>::STEPS; ++st)
+#pragma unroll
+    for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+      for (int ni = 0; ni < NI; ++ni)
+        acc[mi][ni] = Mma<T>::mma(FragSteps<T>::get(a[mi], st), FragSteps<T>::get(b[ni], st), acc[mi][ni]);
+}
+
+
+// The same images with the per-lane source addresses formed ONCE (the address arithmetic of dma_chunk costs more vector
+// instructions per chunk than the MFMAs it feeds).  RPI = rows per LDS-DMA instruction: 8 for 128-byte image rows (slot
+// permutation swz16), 16 for the 64-byte rows of the code images (slot permutation (row >> 2) & 3).
+template <int RPI> __device__ __forceinline__ int dma_slot(int j, int lane) {
+  if (RPI == 8) return (lane & 7) ^ swz16(8 * j + (lane >> 3));
+  return (lane & 3) ^ (((lane >> 2) >> 2) & 3);
+}
+
+// Chunk window advancing ALONG THE ROW (row-major operand, bytes = k): rows outside the matrix are CLAMPED to its last row
+// (they only feed output rows / columns that are never stored); a window completely inside the row is issued
+// unconditionally, the last, partial one lane-checks its 16-byte slot against the row end (slots past it read zeros:
+// reading on would pollute the sum and, on the last row, leave the allocation).
+template <int ROWS, int RPI = 8> struct DmaRowsK {
+  static constexpr int NI = ROWS / RPI;
+  const char* p[NI];
+  int slot16[2];                                  // byte offset of this lane's slot inside the window, even / odd instruction
+  __device__ __forceinline__ void init(const char* __restrict__ g, long ld_bytes, int row0, int nrows, int lane) {
+    const int rl = lane / (64 / RPI);
+#pragma unroll
+    for (int j = 0; j < NI; ++j) {
+      const int rr = min(row0 + RPI * j + rl, nrows - 1);
+      p[j] = g + (long)rr * ld_bytes + 16 * dma_slot<RPI>(j, lane);
+    }
+    slot16[0] = 16 * dma_slot<RPI>(0, lane);
+    slot16[1] = 16 * dma_slot<RPI>(1, lane);
+  }
+  __device__ __forceinline__ void issue_full(int colb0, uint32_t lds) const {
+#pragma unroll
+    for (int j = 0; j < NI; ++j)
+      __builtin_amdgcn_global_load_lds((gbl_cvoid_t*)(p[j] + colb0), (lds_void_t*)(uintptr_t)(lds + j * 1024), 16, 0, 0);
+  }
+  __device__ __forceinline__ void issue_tail(int colb0, int rowbytes, uint32_t lds) const {
+#pragma unroll
+    for (int j = 0; j < NI; ++j) {
+      const char* src = (colb0 + slot16[j & 1] < rowbytes) ? p[j] + colb0 : reinterpret_cast<const char*>(g_zero16);
+      __builtin_amdgcn_global_load_lds((gbl_cvoid_t*)src, (lds_void_t*)(uintptr_t)(lds + j * 1024), 16, 0, 0);
+    }
+  }
+  __device__ __forceinline__ void issue(int colb0, int window, int rowbytes, uint32_t lds) const {
+    if (colb0 + window <= rowbytes) issue_full(colb0, lds);
+    else issue_tail(colb0, rowbytes, lds);
+  }
+};
+
+// Chunk window advancing ALONG THE ROWS (K-major operand: rows = reduction index), fixed byte window [colb0, colb0 + 16 *
+// 64 / RPI) of every row.  Rows >= nrows and bytes >= rowbytes read zeros.  Interior chunks (all rows and the whole window
+// inside the matrix) are issued unconditionally.
+template <int ROWS, int RPI = 8> struct DmaRowsR {
+  static constexpr int NI = ROWS / RPI;
+  const char* p[NI];                              // lane's source for instruction j, chunk row 0 = matrix row 0
+  unsigned colok;                                 // bit j: the lane's slot of instruction j lies inside the row
+  int rl;
+  bool cols_inside;                               // wave-uniform: the whole window lies inside the row
+  __device__ __forceinline__ void init(const char* __restrict__ g, long ld_bytes, int colb0, int rowbytes, int lane) {
+    rl = lane / (64 / RPI);
+    colok = 0;
+    cols_inside = colb0 + 16 * (64 / RPI) <= rowbytes;
+#pragma unroll
+    for (int j = 0; j < NI; ++j) {
+      const int cb = colb0 + 16 * dma_slot<RPI>(j, lane);
+      if (cb < rowbytes) colok |= 1u << j;
+      p[j] = g + (long)(RPI * j + rl) * ld_bytes + cb;
+    }
+  }
+  // r0 = matrix row of the chunk's first row (wave-uniform), adv = r0 * ld_bytes
+  __device__ __forceinline__ void issue(int r0, long adv, int nrows, uint32_t lds) const {
+    if (cols_inside && r0 + ROWS <= nrows) {
+#pragma unroll
+      for (int j = 0; j < NI; ++j)
+        __builtin_amdgcn_global_load_lds((gbl_cvoid_t*)(p[j] + adv), (lds_void_t*)(uintptr_t)(lds + j * 1024), 16, 0, 0);
+    } else {
+#pragma unroll
+      for (int j = 0; j < NI; ++j) {
+        const bool ok = ((colok >> j) & 1u) && (r0 + RPI * j + rl < nrows);
+        const char* src = ok ? p[j] + adv : reinterpret_cast<const char*>(g_zero16);
+        __builtin_amdgcn_global_load_lds((gbl_cvoid_t*)src, (lds_void_t*)(uintptr_t)(lds + j * 1024), 16, 0, 0);
+      }
+    }
+  }
+};
+
+
+#define EMB_WAIT_VMCNT(n) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(n) : "memory")
+
+// wait until at most `chunks` (wave-uniform, 0 .. 3) groups of G vector-memory operations of this wave are outstanding
+template <int G> __device__ __forceinline__ void wait_chunks_in_flight(int chunks) {
+  static_assert(3 * G <= 63, "vmcnt range");
+  if (chunks >= 3) EMB_WAIT_VMCNT(3 * G);
+  else if (chunks == 2) EMB_WAIT_VMCNT(2 * G);
+  else if (chunks == 1) EMB_WAIT_VMCNT(G);
+  else EMB_WAIT_VMCNT(0);
+}
+
+}  // namespace emb

@@ -40,7 +40,7 @@ def _shard_grads(rows, pos_n, seed, step):
     r0, n = rows
     sl = slice(r0, r0 + n)
     gidx = (np.arange(r0, r0 + n, dtype=np.uint64)[:, None] * np.uint64(c) + np.arange(c, dtype=np.uint64)[None, :])
-    u = orc.philox_uniform53(seed, (step << 8) | 0, gidx)
+    u = orc.philox_select_uniform(seed, (step << 8) | 0, gidx)
     idx = orc.embrace_indices(orc.selection_cdf(np.repeat(np.array([[0.4, 0.6]], np.float32), n, 0)), u)
     Xs = [x[sl] for x in X]
     E, Z = orc.embrace_forward(Xs, W, b, idx)

@@ -72,7 +72,9 @@ def test_g1_embracenet_forward_matches_reference(ea, i):
 # ------------------------------------------------------------------------- fwd/bwd vs numpy oracle
 SHAPES = [(8, 4, 64, 32), (64, 16, 1856, 512), (100, 32, 1024, 768), (37, 5, 70, 30), (256, 64, 2048, 256),
           (1024, 16, 1856, 256), (3, 256, 96, 1024),
-          (4096, 16, 1856, 256), (1024, 64, 1024, 1024)]      # full sizes of BASELINE configs 2, 5 (per GPU) and 4
+          (4096, 16, 1856, 256), (1024, 64, 1024, 1024),      # full sizes of BASELINE configs 2, 5 (B=4096 variant) and 4
+          (1024, 16, 1856, 768), (512, 32, 3712, 768),        # cfg3 and cfg5 per-GPU shapes exactly as SURVEY 8d defines them
+          (1017, 16, 1856, 256)]                              # a balanced-sampler batch (ragged against every tile size)
 
 
 @pytest.mark.parametrize("dt", ["f64", "f32", "bf16"])
@@ -170,7 +172,7 @@ def test_philox_mode_matches_oracle_and_is_shard_invariant(ea):
     cdf0, _ = F.select_prep(p, None, B)
     _, code = F.embrace(z, z, w, bz, w, bz, cdf0, rng=F.RngState(seed, step))
     idx = (code & 1).cpu().numpy()
-    u = orc.philox_uniform53(seed, (step << 8) | 0, np.arange(B * c, dtype=np.uint64)).reshape(B, c)
+    u = orc.philox_select_uniform(seed, (step << 8) | 0, np.arange(B * c, dtype=np.uint64)).reshape(B, c)
     want = orc.embrace_indices(orc.selection_cdf(p.cpu().numpy()), u)
     assert np.array_equal(idx, want)
     # two "ranks" of 48 rows each reproduce the single-process result (row0 = global row offset)
@@ -317,6 +319,79 @@ def test_g7_optimizer_steps(ea):
                 if step == 1:
                     assert np.abs(host(p) - g[name + "_p1"]).max() < tol
             assert np.abs(host(p) - g[name + "_p3"]).max() < tol, name
+
+
+@pytest.mark.parametrize("multi", [False, True])
+@pytest.mark.parametrize("dt,tol", [("f64", 1e-13), ("f32", 2e-6)])
+def test_nadam_steps_vs_oracle(ea, multi, dt, tol):
+    """emb_nadam_step / emb_nadam_step_multi against oracle.nadam_step (timm's algorithm; the oracle itself is cross-checked
+    against torch.optim.NAdam on the CPU in tests/test_oracle_golden.py).  Four steps, coupled weight decay on; the multi
+    variant runs through optim.Nadam eagerly and then graph-replayed with the device step counter."""
+    from embracenet_amd import optim, _lib
+    T = TD[dt]
+    lr, wd, sd, n_steps = 3e-3, 2e-2, 4e-3, 4
+    shapes = [(257,), (33, 7), (5,)]
+    ps = [dg.uniform(f"nadam/p{i}", s, -1, 1) for i, s in enumerate(shapes)]
+    gs = [[dg.uniform(f"nadam/g{i}_{t}", s, -1, 1) for i, s in enumerate(shapes)] for t in range(n_steps)]
+    # oracle trajectory (per-parameter m_schedule, all identical by construction)
+    want = []
+    for i, p0 in enumerate(ps):
+        p, m, v, ms = p0.copy(), np.zeros_like(p0), np.zeros_like(p0), 1.0
+        for t in range(n_steps):
+            p, m, v, ms = orc.nadam_step(p, gs[t][i], m, v, t + 1, ms, lr, wd, schedule_decay=sd)
+        want.append(p)
+    if not multi:
+        L, ptr, st = _lib.lib(), _lib.ptr, _lib.stream
+        for i, p0 in enumerate(ps):
+            p = dev(p0, T).contiguous()
+            m, v = torch.zeros_like(p), torch.zeros_like(p)
+            ms = torch.ones(2, dtype=torch.float64, device=DEV)
+            for t in range(n_steps):
+                g_ = dev(gs[t][i], T).contiguous()
+                _lib.check(L.emb_nadam_step(ptr(p), ptr(g_), ptr(m), ptr(v), ptr(ms), None, p.numel(), lr, 0.9, 0.999, 1e-8, wd, sd,
+                                            t + 1, None, _lib.DTYPE_CODE[T], st()), "emb_nadam_step")
+            assert np.abs(host(p) - want[i]).max() < tol, (i, np.abs(host(p) - want[i]).max())
+        return
+    for graph in (False, True):
+        params = [torch.nn.Parameter(dev(p0, T)) for p0 in ps]
+        opt = optim.Nadam(params, lr=lr, weight_decay=wd, schedule_decay=sd)
+        grads = [torch.zeros_like(p) for p in params]
+        for p, g_ in zip(params, grads):
+            p.grad = g_
+        def load(t):
+            for g_, src in zip(grads, gs[t]):
+                g_.copy_(dev(src, T))
+        if not graph:
+            for t in range(n_steps):
+                load(t)
+                opt.step()
+        else:
+            load(0)
+            opt.step()                      # builds the state eagerly (allocation), step 1
+            torch.cuda.synchronize()
+            cg = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(cg):
+                opt.step()                  # captured: the device counter advances inside the graph
+            for t in range(1, n_steps):
+                load(t)
+                cg.replay()
+        for i, p in enumerate(params):
+            e = np.abs(host(p) - want[i]).max()
+            assert e < tol, ("graph" if graph else "eager", i, e)
+
+
+def test_nadam_bf16_shadow_follows_master(ea):
+    """the fused Nadam launch writes the registered bf16 shadow of an fp32 master in place"""
+    from embracenet_amd import optim
+    F = ea.functional
+    p = torch.nn.Parameter(dev(dg.uniform("nadam/sh", (64, 48), -1, 1), torch.float32))
+    sh = F.weight_as(p, torch.bfloat16)
+    opt = optim.Nadam([p], lr=1e-2, weight_decay=1e-2)
+    for t in range(3):
+        p.grad = dev(dg.uniform(f"nadam/shg{t}", (64, 48), -1, 1), torch.float32)
+        opt.step()
+    assert F.shadow_lookup(p) is sh
+    assert torch.equal(sh, p.detach().to(torch.bfloat16))
 
 
 # ------------------------------------------------------------------------------------ fused MLP stack

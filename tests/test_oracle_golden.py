@@ -113,6 +113,29 @@ def test_g7_optimizer_oracle():
         assert np.abs(p - g[name + "_p3"]).max() < 1e-14
 
 
+def test_nadam_oracle_equals_torch_nadam():
+    """oracle.nadam_step restates timm.optim.Nadam (not installable here: timm parity stays formally unpinned).
+    torch.optim.NAdam with momentum_decay = timm's schedule_decay and coupled weight decay implements the same published
+    update (Dozat 2016), so it serves as an independent cross-check of the restatement."""
+    import torch
+    lr, wd, sd = 3e-3, 2e-2, 4e-3
+    p0 = dg.uniform("nadam/cpu/p", (129,), -1, 1)
+    prev = torch.get_default_dtype()
+    torch.set_default_dtype(torch.float64)       # torch keeps its mu_product scalar in the DEFAULT dtype (timm: a Python float)
+    try:
+        tp = torch.nn.Parameter(torch.from_numpy(p0.copy()))
+        opt = torch.optim.NAdam([tp], lr=lr, weight_decay=wd, momentum_decay=sd)
+        p, m, v, ms = p0.copy(), np.zeros_like(p0), np.zeros_like(p0), 1.0
+        for t in range(1, 6):
+            g_ = dg.uniform(f"nadam/cpu/g{t}", (129,), -1, 1)
+            tp.grad = torch.from_numpy(g_.copy())
+            opt.step()
+            p, m, v, ms = orc.nadam_step(p, g_, m, v, t, ms, lr, wd, schedule_decay=sd)
+            assert np.abs(p - tp.detach().numpy()).max() < 1e-15, t
+    finally:
+        torch.set_default_dtype(prev)
+
+
 def test_g8_error_cases():
     with pytest.raises(RuntimeError, match="invalid multinomial distribution"):
         orc.selection_cdf(np.array([[0.0, 1.0], [0.0, 1.0]]), np.array([[1.0, 0.0], [0.0, 1.0]]))
