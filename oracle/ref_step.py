@@ -4,7 +4,7 @@ TEST INFRASTRUCTURE ONLY (see oracle/embrace_oracle.py header).  Used as
   * the full-model oracle for parity tests (pre-nets + embrace + post + loss + grads), and
   * ``bench.py``'s ``cpu_baseline`` leg (kind "port"), timed on the GPU box's host cores.
 It is validated in the build container against the imported reference on identical
-seeded inputs (tests/golden/make_golden.py; tests/test_oracle_vs_reference.py) and
+seeded inputs (tests/golden/make_golden.py asserts oracle == reference while writing the fixtures) and
 pinned on the GPU box by the committed fixtures G2/G3/G9.
 
 Reference citations (relative to /root/reference/BIOINF_tesi/models):

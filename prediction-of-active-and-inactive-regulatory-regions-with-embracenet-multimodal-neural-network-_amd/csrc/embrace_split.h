@@ -73,14 +73,22 @@ __global__ __launch_bounds__(kThreads, 1) void embrace_fwd_split_kernel(
   const int n1 = (d1 + KC - 1) / KC;
   const int n_my = n1 > wave ? (n1 - wave + 3) / 4 : 0;
   const int rowbytes = d1 * (int)sizeof(T);
-  DmaRowsK<TM> dx;
-  DmaRowsK<TN> dw;
-  dx.init(reinterpret_cast<const char*>(X1), (long)rowbytes, row0, B, lane);
-  dw.init(reinterpret_cast<const char*>(W1), (long)rowbytes, col0, c, lane);
+  DmaImage<TM> dx;
+  DmaImage<TN> dw;
+  dx.init((uint32_t)rowbytes, 0, 128, lane);
+  dw.init((uint32_t)rowbytes, 0, 128, lane);
+  const char* Xo = reinterpret_cast<const char*>(X1) + (long)row0 * rowbytes;    // rows >= B / >= c read zeros (range check)
+  const char* Wo = reinterpret_cast<const char*>(W1) + (long)col0 * rowbytes;
+  const long xbytes = (long)(B - row0) * rowbytes, wbytes = (long)(c - col0) * rowbytes;
   auto issue = [&](int i, uint32_t st) {         // i-th chunk of this wave -> stage st
     const int cb = (wave + 4 * i) * 128;
-    dx.issue(cb, 128, rowbytes, st);
-    dw.issue(cb, 128, rowbytes, st + A_BYTES);
+    if (cb + 128 <= rowbytes) {
+      dx.issue(Xo + cb, dma_nrec(xbytes - cb), st);
+      dw.issue(Wo + cb, dma_nrec(wbytes - cb), st + A_BYTES);
+    } else {
+      dx.issue_tail(Xo + cb, dma_nrec(xbytes - cb), rowbytes - cb, st);
+      dw.issue_tail(Wo + cb, dma_nrec(wbytes - cb), rowbytes - cb, st + A_BYTES);
+    }
   };
 #pragma unroll
   for (int s = 0; s < NSTAGE; ++s)

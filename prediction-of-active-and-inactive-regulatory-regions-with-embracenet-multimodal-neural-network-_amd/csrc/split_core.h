@@ -84,87 +84,76 @@ __device__ __forceinline__ void mma_frags(const typename Vec16<T>::type (&a)[MI]
 }
 
 
-// The same images with the per-lane source addresses formed ONCE (the address arithmetic of dma_chunk costs more vector
-// instructions per chunk than the MFMAs it feeds).  RPI = rows per LDS-DMA instruction: 8 for 128-byte image rows (slot
-// permutation swz16), 16 for the 64-byte rows of the code images (slot permutation (row >> 2) & 3).
+// The same images through BUFFER loads (buffer_load_dwordx4 ... offen lds): the matrix is described by a buffer resource in
+// SGPRs, every lane keeps ONE 32-bit byte offset per instruction, formed once per tile, and a chunk is addressed by moving
+// the resource's base (scalar arithmetic) -- no vector instruction per LDS-DMA instruction, and the hardware range check
+// (offset >= num_records reads zeros) covers the rows past the end of the matrix or of a batch slice.  Regions must be
+// smaller than 2 GiB (kDmaInvalid marks lanes that always read zeros).
+// RPI = rows per LDS-DMA instruction: 8 for 128-byte image rows (slot permutation swz16), 16 for the 64-byte rows of the
+// code images (slot permutation (row >> 2) & 3).
+constexpr uint32_t kDmaInvalid = 0x80000000u;
 template <int RPI> __device__ __forceinline__ int dma_slot(int j, int lane) {
   if (RPI == 8) return (lane & 7) ^ swz16(8 * j + (lane >> 3));
   return (lane & 3) ^ (((lane >> 2) >> 2) & 3);
 }
+__device__ __forceinline__ uint32_t dma_nrec(long bytes) { return bytes > 0 ? (uint32_t)bytes : 0u; }
 
-// Chunk window advancing ALONG THE ROW (row-major operand, bytes = k): rows outside the matrix are CLAMPED to its last row
-// (they only feed output rows / columns that are never stored); a window completely inside the row is issued
-// unconditionally, the last, partial one lane-checks its 16-byte slot against the row end (slots past it read zeros:
-// reading on would pollute the sum and, on the last row, leave the allocation).
-template <int ROWS, int RPI = 8> struct DmaRowsK {
+template <int ROWS, int RPI = 8> struct DmaImage {
   static constexpr int NI = ROWS / RPI;
-  const char* p[NI];
-  int slot16[2];                                  // byte offset of this lane's slot inside the window, even / odd instruction
-  __device__ __forceinline__ void init(const char* __restrict__ g, long ld_bytes, int row0, int nrows, int lane) {
+  uint32_t voff[NI];                              // byte offset of this lane's 16 bytes of instruction j from the chunk origin
+  int slot16[2];                                  // byte offset of the lane's slot inside the window, even / odd instruction
+  // the window starts at byte `win0` of a row; slots starting at or beyond byte `rowbytes` of the row read zeros
+  __device__ __forceinline__ void init(uint32_t ld_bytes, int win0, int rowbytes, int lane) {
     const int rl = lane / (64 / RPI);
-#pragma unroll
-    for (int j = 0; j < NI; ++j) {
-      const int rr = min(row0 + RPI * j + rl, nrows - 1);
-      p[j] = g + (long)rr * ld_bytes + 16 * dma_slot<RPI>(j, lane);
-    }
     slot16[0] = 16 * dma_slot<RPI>(0, lane);
     slot16[1] = 16 * dma_slot<RPI>(1, lane);
+#pragma unroll
+    for (int j = 0; j < NI; ++j) {
+      const int cb = win0 + slot16[j & 1];
+      voff[j] = cb < rowbytes ? (uint32_t)(RPI * j + rl) * ld_bytes + (uint32_t)cb : kDmaInvalid;
+    }
   }
-  __device__ __forceinline__ void issue_full(int colb0, uint32_t lds) const {
+  // origin: wave-uniform address of (first image row, byte 0 of the window base); nrec: valid bytes from there on
+  __device__ __forceinline__ void issue(const char* origin, uint32_t nrec, uint32_t lds) const {
+#if defined(__HIP_DEVICE_COMPILE__)   // (the host pass of a kernel TEMPLATE must not see the buffer builtins: it would drop the stub)
+    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)origin, 0, nrec, 0x00020000);
 #pragma unroll
     for (int j = 0; j < NI; ++j)
-      __builtin_amdgcn_global_load_lds((gbl_cvoid_t*)(p[j] + colb0), (lds_void_t*)(uintptr_t)(lds + j * 1024), 16, 0, 0);
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_void_t*)(uintptr_t)(lds + j * 1024), 16, voff[j], 0, 0, 0);
+#endif
   }
-  __device__ __forceinline__ void issue_tail(int colb0, int rowbytes, uint32_t lds) const {
+  // the same for a window whose last `128 - rem` (64 - rem) bytes lie beyond the end of the row: those slots read zeros
+  // (reading on would enter the next row)
+  __device__ __forceinline__ void issue_tail(const char* origin, uint32_t nrec, int rem, uint32_t lds) const {
+#if defined(__HIP_DEVICE_COMPILE__)
+    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)origin, 0, nrec, 0x00020000);
 #pragma unroll
-    for (int j = 0; j < NI; ++j) {
-      const char* src = (colb0 + slot16[j & 1] < rowbytes) ? p[j] + colb0 : reinterpret_cast<const char*>(g_zero16);
-      __builtin_amdgcn_global_load_lds((gbl_cvoid_t*)src, (lds_void_t*)(uintptr_t)(lds + j * 1024), 16, 0, 0);
-    }
-  }
-  __device__ __forceinline__ void issue(int colb0, int window, int rowbytes, uint32_t lds) const {
-    if (colb0 + window <= rowbytes) issue_full(colb0, lds);
-    else issue_tail(colb0, rowbytes, lds);
+    for (int j = 0; j < NI; ++j)
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_void_t*)(uintptr_t)(lds + j * 1024), 16,
+                                               slot16[j & 1] < rem ? voff[j] : kDmaInvalid, 0, 0, 0);
+#endif
   }
 };
 
-// Chunk window advancing ALONG THE ROWS (K-major operand: rows = reduction index), fixed byte window [colb0, colb0 + 16 *
-// 64 / RPI) of every row.  Rows >= nrows and bytes >= rowbytes read zeros.  Interior chunks (all rows and the whole window
-// inside the matrix) are issued unconditionally.
-template <int ROWS, int RPI = 8> struct DmaRowsR {
-  static constexpr int NI = ROWS / RPI;
-  const char* p[NI];                              // lane's source for instruction j, chunk row 0 = matrix row 0
-  unsigned colok;                                 // bit j: the lane's slot of instruction j lies inside the row
-  int rl;
-  bool cols_inside;                               // wave-uniform: the whole window lies inside the row
-  __device__ __forceinline__ void init(const char* __restrict__ g, long ld_bytes, int colb0, int rowbytes, int lane) {
-    rl = lane / (64 / RPI);
-    colok = 0;
-    cols_inside = colb0 + 16 * (64 / RPI) <= rowbytes;
-#pragma unroll
-    for (int j = 0; j < NI; ++j) {
-      const int cb = colb0 + 16 * dma_slot<RPI>(j, lane);
-      if (cb < rowbytes) colok |= 1u << j;
-      p[j] = g + (long)(RPI * j + rl) * ld_bytes + cb;
-    }
-  }
-  // r0 = matrix row of the chunk's first row (wave-uniform), adv = r0 * ld_bytes
-  __device__ __forceinline__ void issue(int r0, long adv, int nrows, uint32_t lds) const {
-    if (cols_inside && r0 + ROWS <= nrows) {
-#pragma unroll
-      for (int j = 0; j < NI; ++j)
-        __builtin_amdgcn_global_load_lds((gbl_cvoid_t*)(p[j] + adv), (lds_void_t*)(uintptr_t)(lds + j * 1024), 16, 0, 0);
-    } else {
-#pragma unroll
-      for (int j = 0; j < NI; ++j) {
-        const bool ok = ((colok >> j) & 1u) && (r0 + RPI * j + rl < nrows);
-        const char* src = ok ? p[j] + adv : reinterpret_cast<const char*>(g_zero16);
-        __builtin_amdgcn_global_load_lds((gbl_cvoid_t*)src, (lds_void_t*)(uintptr_t)(lds + j * 1024), 16, 0, 0);
-      }
-    }
-  }
-};
-
+// ---- diagnostic builds only (-DEMB_SPLIT_PROF, tools/kbench): per-workgroup phase stamps of wave 0 into a debug buffer that
+// nothing else reads.  In the library build EMB_STAMP() is empty and no stamp executes.
+#ifdef EMB_SPLIT_PROF
+__device__ unsigned long long* g_split_prof = nullptr;     // [gridDim][16]: slot 0 job kind, 1 wall clock at entry, 2.. shader clock
+#define EMB_STAMP(k)                                                                                   \
+  do {                                                                                                 \
+    if (g_split_prof != nullptr && threadIdx.x == 0) {                                                 \
+      if ((k) == 2) g_split_prof[(size_t)blockIdx.x * 16 + 1] = __builtin_amdgcn_s_memrealtime();      \
+      g_split_prof[(size_t)blockIdx.x * 16 + (k)] = __builtin_amdgcn_s_memtime();                      \
+    }                                                                                                  \
+  } while (0)
+#define EMB_STAMP_KIND(v)                                                                              \
+  do {                                                                                                 \
+    if (g_split_prof != nullptr && threadIdx.x == 0) g_split_prof[(size_t)blockIdx.x * 16] = (v);      \
+  } while (0)
+#else
+#define EMB_STAMP(k) do { } while (0)
+#define EMB_STAMP_KIND(v) do { } while (0)
+#endif
 
 #define EMB_WAIT_VMCNT(n) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(n) : "memory")
 

@@ -48,8 +48,13 @@ class _RngMixin:
         return self
 
     def _rng_state(self, device):
-        if self._step_dev is None or self._step_dev.device != device:
+        device = torch.device(device)
+        if device.type == "cuda" and device.index is None:      # "cuda" and "cuda:0" name the same counter (as optim._Fused)
+            device = torch.device("cuda", torch.cuda.current_device())
+        if self._step_dev is None:
             self._step_dev = torch.zeros(1, dtype=torch.int64, device=device)
+        elif self._step_dev.device != device:                   # a real device change: the step value moves along
+            self._step_dev = self._step_dev.to(device)
         return F_.RngState(self.rng_seed, 0, self._step_dev, self.rng_row0)
 
     def _advance_step(self):

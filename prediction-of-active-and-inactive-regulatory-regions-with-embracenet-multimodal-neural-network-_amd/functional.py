@@ -81,15 +81,20 @@ _PACKS = {}
 
 
 _PACK_FINALIZERS = set()          # ids of parameters that already carry the clean-up finalizer
+_PACK_REGISTERED = {}             # id(parameter) -> data_ptr currently registered with the library (emb_conv_pack_register)
 
 
-def _pack_drop(key, w_ptr):
+def _pack_drop(key, w_ptr=None):
+    """Forget parameter `key`: drops its images and unregisters WHATEVER pointer is registered for it now (the storage
+    may have moved since the finalizer was armed: model.to(), .float(), ...), plus `w_ptr` if given."""
     _PACKS.pop(key, None)
     _PACK_FINALIZERS.discard(key)
-    try:
-        _lib.lib().emb_conv_pack_unregister(w_ptr)
-    except Exception:
-        pass
+    ptrs = {q for q in (_PACK_REGISTERED.pop(key, None), w_ptr) if q}
+    for q in ptrs:
+        try:
+            _lib.lib().emb_conv_pack_unregister(q)
+        except Exception:
+            pass
 
 
 def conv_packed(w, T, cin_pad, need_flip):
@@ -105,6 +110,7 @@ def conv_packed(w, T, cin_pad, need_flip):
         return ent[2], ent[3]
     if ent is not None:
         _lib.lib().emb_conv_pack_unregister(ent[1][1])
+        _PACK_REGISTERED.pop(id(w), None)
     dev = w.device
     reuse = ent is not None and ent[2].dtype == T and ent[2].shape == (Cout, k * cin_pad) and ent[2].device == dev
     wpack = ent[2] if reuse else torch.empty(Cout, k * cin_pad, dtype=T, device=dev)
@@ -117,9 +123,10 @@ def conv_packed(w, T, cin_pad, need_flip):
           "emb_conv_pack_weight")
     if T == torch.bfloat16 and w.dtype == torch.float32 and wd.data_ptr() == w.data_ptr():
         check(_lib.lib().emb_conv_pack_register(w.data_ptr(), ptr(wpack), ptr(wflip), Cout, Cin, cin_pad, k), "emb_conv_pack_register")
+        _PACK_REGISTERED[id(w)] = w.data_ptr()
         if id(w) not in _PACK_FINALIZERS:           # the table entry must not outlive the parameter's storage
             _PACK_FINALIZERS.add(id(w))
-            weakref.finalize(w, _pack_drop, id(w), w.data_ptr())
+            weakref.finalize(w, _pack_drop, id(w))  # (looks the registered pointer up when the parameter dies)
     _PACKS[id(w)] = (weakref.ref(w), key, wpack, wflip)
     return wpack, wflip
 
@@ -533,6 +540,7 @@ def cast(src, dtype, out=None):
 # autograd node; activations are channels-last between blocks, the last block emits the reference's
 # [B, C*Lp] flatten order.
 _WORKSPACE = {}
+_RETIRED_WORKSPACES = []          # outgrown scratch buffers, kept alive for graphs captured on them (see _workspace)
 
 
 def reduce_defer(enable):
@@ -553,6 +561,12 @@ def _workspace(device, nbytes, tag=""):
     key = (torch.device(device), tag)
     buf = _WORKSPACE.get(key)
     if buf is None or buf.numel() < nbytes:
+        if buf is not None:
+            # A captured step graph (training.StepRunner) may have baked this buffer's address in and will keep writing
+            # partial sums there on every replay: a retired buffer is never handed back to the allocator.  Growth is
+            # geometric, so the retired total stays below the size of the live buffer.
+            _RETIRED_WORKSPACES.append(buf)
+            nbytes = max(int(nbytes), (3 * buf.numel()) // 2)
         buf = torch.empty(int(nbytes), dtype=torch.uint8, device=device)
         _WORKSPACE[key] = buf
     return buf

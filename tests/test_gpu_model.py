@@ -346,3 +346,103 @@ def test_graph_steps_follow_a_changing_learning_rate(ea):
     assert n_graphs == 3 and np.array_equal(la, lb)
     for k in sa:
         assert torch.equal(sa[k], sb[k]), k
+
+
+# ------------------------------------------------------------------------- bf16 full model at BASELINE config 2
+@pytest.mark.parametrize("mode", ["eval", "train"])
+def test_bf16_full_model_logits_at_cfg2_vs_oracle(ea, mode):
+    """BASELINE configs[1] as benchmarked: cfg1's networks with c = 256, B = 1024, bf16 storage / fp32 accumulation.
+    Oracle = oracle/ref_step.py in fp64 fed the SAME bf16-rounded parameters and inputs ("fp64 reference vs
+    fp32/bf16 build").  Host-RNG mode, so the index tensor is bit-exact; logits agree to 3e-2 of the logit scale: the
+    HIP path rounds six intermediate activations to bf16 (2^-9 relative each: three FFNN layers, two pooled conv blocks, E)
+    on top of bf16 products accumulated in fp32 -- measured error is ~1e-2.  Train mode adds batch-statistics BatchNorm and
+    the modality-dropout draws of EmbraceNetMultimodal.py:178-182."""
+    from oracle import ref_step
+    from oracle.configs import CFG1
+    from embracenet_amd import training
+    hp, F_in, B = dict(CFG1, EMBRACENET_embracement_size=256), 48, 1024
+    bf = lambda a: torch.from_numpy(np.asarray(a, dtype=np.float64)).to(torch.bfloat16).double().numpy()
+    fill = model_fill("bf16cfg2")
+    rfill = lambda key, shape: bf(fill(key, shape))
+    oracle_m = ref_step.OracleEmbraceNetMultimodal(hp, F_in)
+    oracle_m.set_tensors(rfill)
+    model = ea.EmbraceNetMultimodal(FixedTrial(hp), cell_line="A549", task="active_E_vs_inactive_E", device=DEV,
+                                    in_features_FFNN=F_in).double()
+    with torch.no_grad():
+        for key, t in model.state_dict().items():
+            if "running_" not in key and "num_batches" not in key:
+                t.copy_(torch.from_numpy(rfill(key, tuple(t.shape))))
+    model = training.prepare_model(model, DEV, "bfloat16").set_rng("host")
+    x1, x2, _ = model_batch("bf16cfg2/B1024", B, F_in, 0.1)
+    x1 = bf(x1)
+    seeds = (3,) if mode == "eval" else (0, 1, 2, 3)        # train: cover both branches of the modality-dropout gate
+    branches = set()
+    for seed in seeds:
+        if mode == "eval":
+            oracle_m.eval(); model.eval()
+        else:
+            oracle_m.train(); model.train()
+        torch.manual_seed(seed)
+        with torch.no_grad():
+            want = oracle_m([torch.from_numpy(x1), torch.from_numpy(x2)], is_training=(mode == "train")).numpy()
+        branches.add(oracle_m.last["t"] is not None)
+        torch.manual_seed(seed)
+        with torch.no_grad():
+            got = model([torch.from_numpy(x1).to(DEV, torch.bfloat16), torch.from_numpy(x2).to(DEV, torch.bfloat16)],
+                        is_training=(mode == "train"))
+        assert np.array_equal(model.embracenet.modality_indices().cpu().numpy(), oracle_m.last["idx"].numpy()), (mode, seed)
+        got = got.double().cpu().numpy()
+        scale = max(1.0, np.abs(want).max())
+        err = np.abs(got - want).max() / scale
+        assert err < 3e-2, (mode, seed, err)
+        assert (np.argmax(got, 1) == np.argmax(want, 1)).mean() > 0.97
+    if mode == "train":
+        assert branches == {True, False}, "seeds no longer cover both modality-dropout branches"
+
+
+# ------------------------------------------------------------------------- Param_Search_Multimodal.objective
+class _ObjectiveTrial(FixedTrial):
+    """FixedTrial plus the part of optuna's trial API that Param_Search_Multimodal.objective touches
+    (training_models_multimodal.py:307-415): report / should_prune / number / log-uniform suggestions."""
+
+    def __init__(self, params, number=7):
+        super().__init__(params)
+        self.number, self.reported = number, []
+
+    def suggest_float(self, name, low, high, log=False):
+        return self._get(name)
+
+    def suggest_loguniform(self, name, low, high):
+        return self._get(name)
+
+    def report(self, value, step):
+        self.reported.append((step, float(value)))
+
+    def should_prune(self):
+        return False
+
+
+@pytest.mark.parametrize("opt_name", ["Nadam", "Adam", "RMSprop"])
+def test_param_search_objective_with_a_fixed_trial(ea, opt_name, tmp_path):
+    """One trial of the reference's search loop (training_models_multimodal.py:307-415) on device loaders: builds the model
+    from the trial, draws optimizer / lr / weight_decay in the reference's order, trains with per-epoch report, saves the
+    whole model.  Each of the three optimizers of the search space (:318-325) is exercised."""
+    from embracenet_amd import data, training
+    hp, F_in = CONFIGS["small"]
+    mk = lambda tag, n: (dg.uniform(f"ps/{tag}/x1", (n, F_in)), dg.onehot_sequence(f"ps/{tag}/seq", n), dg.labels(f"ps/{tag}/y", n, 0.3))
+    xtr, str_, ytr = mk("train", 160)
+    xte, ste, yte = mk("test", 64)
+    train = data.device_loaders(xtr, str_, ytr, 32, DEV, balanced=True, random_state=123, feature_dtype=torch.float32)
+    test = data.device_loaders(xte, ste, yte, 64, DEV, balanced=False, random_state=153, feature_dtype=torch.float32)
+    ps = training.Param_Search_Multimodal(ea.EmbraceNetMultimodal, train, test, num_epochs=2, study_name=str(tmp_path / "study_"),
+                                          device=DEV, cell_line="A549", task="active_E_vs_inactive_E", precision="float32")
+    trial = _ObjectiveTrial(dict(hp, optimizer=opt_name, lr=2e-3, weight_decay=1e-3))
+    score = ps.objective(trial)
+    n_model = len([c for c in trial.calls if c not in ("optimizer", "lr", "weight_decay")])
+    assert trial.calls[n_model:] == ["optimizer", "lr", "weight_decay"], "optimizer draws must follow the model's (:318-321)"
+    assert [s_ for s_, _ in trial.reported] == [1, 2] and trial.reported[-1][1] == score
+    assert 0.0 <= score <= 1.0 and np.isfinite(score)
+    saved = torch.load(str(tmp_path / "study_") + "7.pt", weights_only=False)
+    assert type(saved).__name__ == "EmbraceNetMultimodal"
+    for a, b in zip(saved.state_dict().values(), ps.model.state_dict().values()):
+        assert torch.equal(a.cpu(), b.cpu())

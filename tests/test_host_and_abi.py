@@ -175,3 +175,16 @@ def test_native_shuffle_equals_python_random_on_long_lists():
             got = np.arange(n, dtype=np.int64)
             sh.shuffle(got)
             assert got.tolist() == want, (seed, n)
+
+
+def test_library_has_no_undefined_internal_symbols():
+    """ctypes binds lazily, so a kernel host stub the compiler silently dropped (seen once: buffer builtins in the host pass
+    of a kernel template) would only fail at its first launch on the GPU box.  Catch it here: nothing in namespace emb may
+    be left undefined in the shared object."""
+    import shutil
+    import subprocess
+    from embracenet_amd import _lib
+    nm = shutil.which("nm") or "/opt/rocm/lib/llvm/bin/llvm-nm"
+    out = subprocess.run([nm, "-D", "--undefined-only", _lib.LIB_PATH], capture_output=True, text=True, check=True).stdout
+    bad = [l for l in out.splitlines() if "_ZN3emb" in l]
+    assert not bad, bad[:5]
