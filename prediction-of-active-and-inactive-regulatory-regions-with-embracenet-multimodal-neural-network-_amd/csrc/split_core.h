@@ -98,19 +98,25 @@ template <int RPI> __device__ __forceinline__ int dma_slot(int j, int lane) {
 }
 __device__ __forceinline__ uint32_t dma_nrec(long bytes) { return bytes > 0 ? (uint32_t)bytes : 0u; }
 
-template <int ROWS, int RPI = 8> struct DmaImage {
-  static constexpr int NI = ROWS / RPI;
-  uint32_t voff[NI];                              // byte offset of this lane's 16 bytes of instruction j from the chunk origin
-  int slot16[2];                                  // byte offset of the lane's slot inside the window, even / odd instruction
+template <int ROWS, int RPI = 8, int JS = 1> struct DmaImage {
+  static constexpr int NI = ROWS / RPI;           // LDS-DMA instructions of the whole image
+  static constexpr int NJ = NI / JS;              // ... of which this wave issues j = j0, j0 + JS, ... (JS = 1: all)
+  static_assert(NI % JS == 0 && (JS == 1 || JS % 2 == 0), "instruction split");
+  uint32_t voff[NJ];                              // byte offset of this lane's 16 bytes of its i-th instruction from the chunk origin
+  int slot16;                                     // byte offset of the lane's slot inside the window (JS > 1: one parity only)
+  int slot16_odd;                                 // JS == 1: the slot of odd instructions
+  int j0;
   // the window starts at byte `win0` of a row; slots starting at or beyond byte `rowbytes` of the row read zeros
-  __device__ __forceinline__ void init(uint32_t ld_bytes, int win0, int rowbytes, int lane) {
+  __device__ __forceinline__ void init(uint32_t ld_bytes, int win0, int rowbytes, int lane, int j0_ = 0) {
     const int rl = lane / (64 / RPI);
-    slot16[0] = 16 * dma_slot<RPI>(0, lane);
-    slot16[1] = 16 * dma_slot<RPI>(1, lane);
+    j0 = j0_;
+    slot16 = 16 * dma_slot<RPI>(j0, lane);
+    slot16_odd = 16 * dma_slot<RPI>(j0 + 1, lane);
 #pragma unroll
-    for (int j = 0; j < NI; ++j) {
-      const int cb = win0 + slot16[j & 1];
-      voff[j] = cb < rowbytes ? (uint32_t)(RPI * j + rl) * ld_bytes + (uint32_t)cb : kDmaInvalid;
+    for (int i = 0; i < NJ; ++i) {
+      const int j = j0 + i * JS;
+      const int cb = win0 + ((JS == 1 && (i & 1)) ? slot16_odd : slot16);
+      voff[i] = cb < rowbytes ? (uint32_t)(RPI * j + rl) * ld_bytes + (uint32_t)cb : kDmaInvalid;
     }
   }
   // origin: wave-uniform address of (first image row, byte 0 of the window base); nrec: valid bytes from there on
@@ -118,8 +124,8 @@ template <int ROWS, int RPI = 8> struct DmaImage {
 #if defined(__HIP_DEVICE_COMPILE__)   // (the host pass of a kernel TEMPLATE must not see the buffer builtins: it would drop the stub)
     const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)origin, 0, nrec, 0x00020000);
 #pragma unroll
-    for (int j = 0; j < NI; ++j)
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_void_t*)(uintptr_t)(lds + j * 1024), 16, voff[j], 0, 0, 0);
+    for (int i = 0; i < NJ; ++i)
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_void_t*)(uintptr_t)(lds + (j0 + i * JS) * 1024), 16, voff[i], 0, 0, 0);
 #endif
   }
   // the same for a window whose last `128 - rem` (64 - rem) bytes lie beyond the end of the row: those slots read zeros
@@ -128,9 +134,9 @@ template <int ROWS, int RPI = 8> struct DmaImage {
 #if defined(__HIP_DEVICE_COMPILE__)
     const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)origin, 0, nrec, 0x00020000);
 #pragma unroll
-    for (int j = 0; j < NI; ++j)
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_void_t*)(uintptr_t)(lds + j * 1024), 16,
-                                               slot16[j & 1] < rem ? voff[j] : kDmaInvalid, 0, 0, 0);
+    for (int i = 0; i < NJ; ++i)
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_void_t*)(uintptr_t)(lds + (j0 + i * JS) * 1024), 16,
+                                               ((JS == 1 && (i & 1)) ? slot16_odd : slot16) < rem ? voff[i] : kDmaInvalid, 0, 0, 0);
 #endif
   }
 };

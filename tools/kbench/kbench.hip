@@ -99,8 +99,8 @@ int main(int argc, char** argv) {
   if (bwd) {
     launch = [&] { if (emb::bwd_split_dispatch(dE, code, X0, X1, W0, W1, dX0, dX1, dW0, db0, dW1, db1, ws, ws_bytes, B, d0, d1, c, S, s) != 0) { printf("dispatch refused\n"); exit(1); } };
     int occ = 0;
-    CK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, emb::embrace_bwd_split_kernel, 256, 81920));
-    printf("occupancy query (bwd, 80 KB LDS): %d blocks/CU\n", occ);
+    CK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, emb::embrace_bwd_split_kernel, emb::kBwdThreads, emb::kBwdLds));
+    printf("occupancy query (bwd): %d blocks/CU\n", occ);
   } else {
     launch = [&] { if (emb::fwd_split_dispatch<__bf16>(X0, X1, W0, b0, W1, b1, sel, nullptr, 7, 1, nullptr, 0, E, code, B, d0, d1, c, s) != 0) { printf("dispatch refused\n"); exit(1); } };
   }
