@@ -144,6 +144,53 @@ class FlatGrads:
             dist.all_reduce(self.flat, op=dist.ReduceOp.SUM)
 
 
+class BucketedFlatGrads:
+    """FlatGrads in TWO buckets so that the reduction of the first overlaps the rest of the backward pass:
+    "early" = parameters whose gradients are complete once the fusion layer's backward has been enqueued (post stack,
+    classifier head, docking layers), "late" = the pre-networks.  `allreduce_early()` issues the first collective
+    asynchronously (RCCL runs it on its own stream behind the work enqueued so far), `finish()` waits for it and reduces the
+    second bucket.  Both are capturable into a step graph with the RCCL backend."""
+
+    def __init__(self, model):
+        early, late = [], []
+        for name, p in model.named_parameters():
+            if p.requires_grad:
+                (early if name.startswith(("embracenet.", "post.")) else late).append(p)
+        self.early = FlatGrads(early) if early else None
+        self.late = FlatGrads(late) if late else None
+        self._work = None
+
+    def buckets(self):
+        return [b for b in (self.early, self.late) if b is not None]
+
+    def allreduce_early(self):
+        if self.early is not None and world_size() > 1:
+            self._work = dist.all_reduce(self.early.flat, op=dist.ReduceOp.SUM, async_op=True)
+
+    def finish(self):
+        if world_size() == 1:
+            return
+        if self._work is not None:
+            self._work.wait()
+            self._work = None
+        elif self.early is not None:                 # the early hook did not fire (no fusion layer in the model)
+            dist.all_reduce(self.early.flat, op=dist.ReduceOp.SUM)
+        if self.late is not None:
+            dist.all_reduce(self.late.flat, op=dist.ReduceOp.SUM)
+
+    def zero_(self):
+        for b in self.buckets():
+            b.flat.zero_()
+
+
+def broadcast_buffers(model, src=0):
+    """Make every rank hold rank `src`'s module buffers (BatchNorm running statistics differ per rank under local
+    statistics): called before a checkpoint is written / a fit returns, so that all replicas evaluate alike."""
+    if world_size() > 1:
+        for b in model.buffers():
+            dist.broadcast(b, src)
+
+
 def barrier():
     if world_size() > 1:
         dist.barrier()

@@ -251,11 +251,24 @@ class _EmbraceFn(torch.autograd.Function):
         check(_lib.lib().emb_embrace_bwd(ptr(dE), ptr(code), ptr(x0c), ptr(x1c), ptr(w0c), ptr(w1c), ptr(dX0), ptr(dX1),
                                          ptr(dW0), ptr(db0), ptr(dW1), ptr(db1), ptr(ws), ws.numel(), B, d0, d1, c,
                                          DTYPE_CODE[T], stream()), "emb_embrace_bwd")
+        if _AFTER_EMBRACE_BWD is not None:
+            _AFTER_EMBRACE_BWD()
         t = ctx.in_dtypes
         cast = lambda g, d: None if g is None else (g if g.dtype == d else g.to(d))
         ret = lambda g, d, sink: None if sink is not None else cast(g, d)
         return (cast(dX0, t[0]), cast(dX1, t[1]), ret(dW0, t[2], sk[0]), ret(db0, t[3], sk[1]), ret(dW1, t[4], sk[2]),
                 ret(db1, t[5], sk[3]), None, None, None, None)
+
+
+_AFTER_EMBRACE_BWD = None
+
+
+def set_after_embrace_backward(fn):
+    """`fn()` is called right after the fusion layer's backward kernels have been enqueued -- the point of the backward
+    pass at which every gradient of the post stack, the head and the docking layers is on its way (a data-parallel trainer
+    starts reducing them there, training.StepRunner).  None clears the hook."""
+    global _AFTER_EMBRACE_BWD
+    _AFTER_EMBRACE_BWD = fn
 
 
 def embrace(x0, x1, w0, b0, w1, b1, cdf0, u=None, rng=None, compute_dtype=None):

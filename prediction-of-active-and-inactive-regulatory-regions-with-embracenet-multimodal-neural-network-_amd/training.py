@@ -106,7 +106,13 @@ class StepRunner:
         self.graph = GRAPH_STEPS if graph is None else bool(graph)
         self._graphs = {}
         self.fuse_loss = True
-        self.bucket = D.GradBucket(model.parameters()) if optimizer is not None else None
+        on_gpu_ = torch.device(device).type == "cuda"
+        # data parallel on the GPU: every gradient is a view of one of two flat buffers the backward kernels write directly;
+        # the first bucket (post stack, head, docking) is all-reduced while the pre-networks' backward still runs
+        self.flat = D.BucketedFlatGrads(model) if (optimizer is not None and D.world_size() > 1 and on_gpu_
+                                                   and next(model.parameters()).is_cuda) else None
+        self.bucket = D.GradBucket(model.parameters()) if (optimizer is not None and self.flat is None) else None
+        self._redundant = False
         self.counts = torch.zeros(2, dtype=torch.int64, device=device)
         on_gpu = torch.device(device).type == "cuda"
         self.model_tick = model.step_counter(device) if (on_gpu and hasattr(model, "step_counter")) else None
@@ -115,17 +121,40 @@ class StepRunner:
     def _shard(self, x_1, x_2, target):
         world = D.world_size()
         B = x_1.shape[0]
+        self._redundant = False
         if world == 1:
+            return x_1, x_2, target, 0
+        if B < world:
+            # fewer rows than ranks (a ragged last batch): an empty shard cannot run the kernels and must not leave its
+            # peers waiting in a collective.  Every rank knows B, so every rank takes the same branch: all process the whole
+            # (tiny) batch, and only rank 0's loss share, counts and gradients enter the sums (_drop_redundant).
+            self._redundant = True
             return x_1, x_2, target, 0
         row0, rows = D.shard_rows(B, D.rank(), world)
         sl = slice(row0, row0 + rows)
         return x_1[sl], x_2[sl], target[sl], row0
 
+    def _drop_redundant(self, table_slots=None):
+        """redundant-batch mode: ranks other than 0 contribute zeros"""
+        if not self._redundant or D.rank() == 0:
+            return
+        if table_slots is not None:
+            for t in table_slots:
+                t.zero_()
+        if self.flat is not None:
+            self.flat.zero_()
+        elif self.bucket is not None:
+            for p in self.bucket.params:
+                if p.grad is not None:
+                    p.grad.zero_()
+
     # ---- hipGraph replay of whole steps ---------------------------------------------------------------------------------
     def _graphable(self, training):
         m = self.model
-        if not (self.graph and torch.device(self.device).type == "cuda" and D.world_size() == 1):
+        if not (self.graph and torch.device(self.device).type == "cuda"):
             return False
+        if D.world_size() > 1 and not (self.flat is not None and torch.distributed.get_backend() == "nccl"):
+            return False                                    # collectives of other backends cannot be captured
         if getattr(m, "rng_mode", None) != "philox" or self.model_tick is None:
             return False
         return (not training) or self.opt_tick is not None
@@ -202,7 +231,7 @@ class StepRunner:
         tgt = target.to(dev, non_blocking=True).reshape(-1)
         if hasattr(model, "rng_row0"):
             model.rng_row0 = row0
-        global_counts = D.world_size() > 1
+        global_counts = D.world_size() > 1 and not self._redundant
         if global_counts:                                   # class weights of the GLOBAL batch
             F_.count_labels(tgt, out=self.counts)
             D.allreduce_counts(self.counts)
@@ -215,12 +244,17 @@ class StepRunner:
         fused = self.fuse_loss and hasattr(model, "fused_loss_ready") and model.fused_loss_ready(x_1.shape[0])
         if fused:
             model.arm_fused_loss(F_.FusedLoss(tgt, self.counts, global_counts, loss_slot, count_slot, ticks))
+        sync_mods = [m for m in model.modules() if getattr(m, "sync_batchnorm", False)] if self._redundant else []
+        for m in sync_mods:
+            m.sync_batchnorm = False                        # every rank holds the whole batch: nothing to exchange
         try:
             if training and _is_embracenet(model):
                 output = model([x_1, x_2], is_training=True)
             else:
                 output = model([x_1, x_2])
         finally:
+            for m in sync_mods:
+                m.sync_batchnorm = True
             if self.model_tick is not None:
                 model.defer_step_tick = prev
             if fused:
@@ -240,23 +274,37 @@ class StepRunner:
         return done if done is not None else self._eval_step_eager(x_1, x_2, target, table)
 
     def _train_step_eager(self, x_1, x_2, target, table, set_to_none=None):
-        if set_to_none is None:
+        if self.flat is not None:
+            pass                        # gradients live in the flat buckets and are overwritten by every backward pass
+        elif set_to_none is None:
             self.optimizer.zero_grad()
         else:
             self.optimizer.zero_grad(set_to_none=set_to_none)
+        slots_before = table.n
         output, loss, dlogits = self._forward_loss(x_1, x_2, target, True, table)
         deferred = output.is_cuda
         if deferred:
             F_.reduce_defer(True)       # the per-layer slab reductions of the backward are queued ...
+        if self.flat is not None and not self._redundant:
+            def early():                # fusion layer's backward is enqueued: its slabs, then the first bucket's all-reduce
+                F_.reduce_flush()
+                self.flat.allreduce_early()
+            F_.set_after_embrace_backward(early)
         try:
             # the loss is the root of the graph: d loss / d logits comes from the loss kernel (or, fused, is already inside
             # the head's node, which ignores what it is handed)
             output.backward(dlogits if dlogits is not None else output.detach())
         finally:
+            F_.set_after_embrace_backward(None)
             if deferred:
                 F_.reduce_defer(False)
                 F_.reduce_flush()       # ... and run in one launch here
-        self.bucket.allreduce()
+        if self._redundant:
+            self._drop_redundant((table.loss[slots_before:table.n], table.counts[slots_before:table.n]))
+        if self.flat is not None:
+            self.flat.finish()
+        else:
+            self.bucket.allreduce()
         if self.opt_tick is not None:
             self.optimizer.external_tick = True             # already advanced by the loss kernel of this step
         try:
@@ -267,8 +315,11 @@ class StepRunner:
         return output, loss
 
     def _eval_step_eager(self, x_1, x_2, target, table):
+        slots_before = table.n
         with torch.no_grad():
             output, loss, _ = self._forward_loss(x_1, x_2, target, False, table)
+        if self._redundant:
+            self._drop_redundant((table.loss[slots_before:table.n], table.counts[slots_before:table.n]))
         return output, loss
 
 
@@ -338,7 +389,7 @@ def fit_multimodal(model, train_loader, test_loader, device, cell_line, task, op
         AUPRC_train_scores.append(AUPRC_train)
         AUPRC_test_scores.append(AUPRC_test)
         F1_precision_recall_test_scores.append(F1_precision_recall_test)
-        if verbose is True:
+        if verbose is True and D.rank() == 0:
             print('Epoch: {} \tTraining AUPRC score: {:.4f} \tTest AUPRC score: {:.4f} \tTraining Loss: {:.4f} '
                   '\tTest Loss: {:.4f}'.format(epoch, AUPRC_train, AUPRC_test, train_loss, test_loss))
         early_stopping(AUPRC_test)
@@ -346,10 +397,13 @@ def fit_multimodal(model, train_loader, test_loader, device, cell_line, task, op
             print('Early stopping the training')
             break
 
+    D.broadcast_buffers(model)                               # BatchNorm running statistics: every replica ends with rank 0's
     if checkpoint_path:
-        torch.save({'model_state_dict': model.state_dict(), 'AUPRC_train_scores': AUPRC_train_scores,
-                    'AUPRC_test_scores': AUPRC_test_scores,
-                    'F1_precision_recall_test_scores': F1_precision_recall_test_scores}, checkpoint_path)
+        if D.rank() == 0:                                    # one writer; the others wait for the file to be complete
+            torch.save({'model_state_dict': model.state_dict(), 'AUPRC_train_scores': AUPRC_train_scores,
+                        'AUPRC_test_scores': AUPRC_test_scores,
+                        'F1_precision_recall_test_scores': F1_precision_recall_test_scores}, checkpoint_path)
+        D.barrier()
     return AUPRC_train_scores, AUPRC_test_scores, F1_precision_recall_test_scores
 
 

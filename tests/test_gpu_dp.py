@@ -35,22 +35,30 @@ def _run(world, rank, port, precision, out):
     dist.set_sync_batchnorm(model)
     opt = optim.Adam(model.parameters(), lr=1e-3, weight_decay=1e-3)
     runner = training.StepRunner(model, opt, dev)
-    table = ea.metrics.StepTable(STEPS + 1, dev)
+    table = ea.metrics.StepTable(STEPS + 3, dev)
     model.train()
     cast = torch.float64 if precision == "float64" else torch.float32
     for k in range(STEPS):
         a, b, y = model_batch(f"dpgpu/{k}", B, F_in, 0.3)
         runner.train_step(torch.from_numpy(a).to(cast), torch.from_numpy(b).to(cast), torch.from_numpy(y), table)   # the GLOBAL batch
+    np.save(out + f".idx{rank}.npy", model.embracenet.modality_indices().cpu().numpy())      # selection of the last sharded step, local rows
+    # a global batch with fewer rows than ranks (ragged last batch): every rank runs it whole, rank 0 alone contributes
+    a, b, y = model_batch("dpgpu/tiny", 1, F_in, 0.3)
+    runner.train_step(torch.from_numpy(a).to(cast), torch.from_numpy(b).to(cast), torch.from_numpy(y), table)
+    runner.eval_step(torch.from_numpy(a).to(cast), torch.from_numpy(b).to(cast), torch.from_numpy(y), table)
     losses, counts = table.fetch()
-    np.save(out + f".idx{rank}.npy", model.embracenet.modality_indices().cpu().numpy())      # selection of the last step, local rows
     if world > 1:                                                # per-shard loss shares / counts -> global
         t = torch.from_numpy(np.concatenate([losses, counts.reshape(-1).astype(np.float64)]))
         torch.distributed.all_reduce(t)
-        losses, counts = t[:STEPS].numpy(), t[STEPS:].numpy().reshape(-1, 4)
+        losses, counts = t[:STEPS + 2].numpy(), t[STEPS + 2:].numpy().reshape(-1, 4)
     if rank == 0:
         np.savez(out, losses=losses, counts=counts,
                  **{k.replace(".", "__"): v.detach().double().cpu().numpy() for k, v in model.state_dict().items()})
     if world > 1:
+        assert runner.flat is not None and len(runner.flat.buckets()) == 2, "two-bucket flat gradients expected under DP"
+        for p in model.parameters():                             # gradients are views of the flat buckets
+            assert any(p.grad.data_ptr() >= bk.flat.data_ptr() and
+                       p.grad.data_ptr() < bk.flat.data_ptr() + bk.flat.numel() * bk.flat.element_size() for bk in runner.flat.buckets())
         torch.distributed.barrier()
         torch.distributed.destroy_process_group()
 

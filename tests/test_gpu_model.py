@@ -348,6 +348,38 @@ def test_graph_steps_follow_a_changing_learning_rate(ea):
         assert torch.equal(sa[k], sb[k]), k
 
 
+def test_captured_steps_survive_workspace_growth_and_cache_release(ea):
+    """A captured step graph has the scratch buffers' addresses baked in.  Larger batches arriving later (the test loader
+    runs at twice the train batch, BalancePos batches differ by a row) must not hand those buffers back to the allocator:
+    capture at B, run B + 1 and 2B eagerly (workspaces grow), release the cache, let new long-lived tensors take whatever
+    was freed, replay the B graph -- parameters must equal the all-eager run bit for bit."""
+    from embracenet_amd import optim, training
+    def run(graph):
+        model, trial, hp, F_in = build(ea, "small", "wsg", torch.float32)
+        model.set_rng("philox", seed=31)
+        model = training.prepare_model(model, DEV, "float32")
+        opt = optim.Adam(model.parameters(), lr=1e-3)
+        runner = training.StepRunner(model, opt, DEV, graph=graph)
+        table = ea.metrics.StepTable(64, DEV)
+        model.train()
+        keep = []
+        sizes = [48] * 4 + [49, 96] + [48] * 4                  # capture happens at the third 48-row step
+        for k, bs in enumerate(sizes):
+            a, b, y = model_batch(f"wsg/{bs}", bs, F_in, 0.3)
+            runner.train_step(torch.from_numpy(a).float(), torch.from_numpy(b).float(), torch.from_numpy(y), table)
+            if k == 5:                                          # after the larger batches: free what can be freed, then occupy it
+                torch.cuda.synchronize()
+                torch.cuda.empty_cache()
+                keep = [torch.full((1 << 18,), 7.0, device=DEV) for _ in range(24)]
+        torch.cuda.synchronize()
+        assert all(bool((t == 7.0).all()) for t in keep), "a replayed graph wrote into memory it no longer owns"
+        return table.fetch()[0], {k: v.detach().cpu().clone() for k, v in model.state_dict().items()}, len(runner._graphs)
+    (la, sa, _), (lb, sb, n_graphs) = run(False), run(True)
+    assert n_graphs >= 1 and np.array_equal(la, lb)
+    for k in sa:
+        assert torch.equal(sa[k], sb[k]), k
+
+
 # ------------------------------------------------------------------------- bf16 full model at BASELINE config 2
 @pytest.mark.parametrize("mode", ["eval", "train"])
 def test_bf16_full_model_logits_at_cfg2_vs_oracle(ea, mode):
