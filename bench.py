@@ -288,8 +288,8 @@ def single_gpu_rate(ea, wl, dtype, device, steps=60, warmup=10):
         F.reduce_defer(True)
         out.backward(dlogits)
         F.reduce_defer(False)
-        F.reduce_flush()
-        opt.step()
+        opt.step()                                        # sums the queued gradient slabs inside its own launch
+        F.reduce_flush()                                  # (nothing left: no launch)
 
     side = torch.cuda.Stream()
     side.wait_stream(torch.cuda.current_stream())
@@ -458,10 +458,11 @@ def main():
         else:
             _, dlogits = F.weighted_ce_with_grad(out, y, class_counts=counts, global_counts=dist_path, confusion=conf_slot,
                                                  loss_out=loss_slot, ticks=ticks)
-        F.reduce_defer(True)                              # one reduction launch for all weight-gradient slabs of the backward
-        out.backward(dlogits)
-        F.reduce_defer(False)
-        F.reduce_flush()
+        F.reduce_defer(True)                              # the weight-gradient slabs of the backward are queued: one process ->
+        out.backward(dlogits)                             # the optimizer launch sums them; N > 1 -> one reduction launch, since
+        F.reduce_defer(False)                             # the all-reduce needs finished gradients
+        if dist_path:
+            F.reduce_flush()
 
     def reduce_grads():
         flat.extra.copy_(local_counts)                    # next batch's labels (synthetic: the same batch)
@@ -472,11 +473,16 @@ def main():
         F.count_labels(y, out=counts)
         D.allreduce_counts(counts)
 
+    def opt_step():
+        opt.step()
+        if not dist_path:
+            F.reduce_flush()                              # whatever the optimizer launch did not take (nothing: no launch)
+
     def eager_step():
         fwd_bwd()
         if flat is not None:
             reduce_grads()
-        opt.step()
+        opt_step()
 
     side = torch.cuda.Stream()
     side.wait_stream(torch.cuda.current_stream())
@@ -498,7 +504,7 @@ def main():
             g_all = torch.cuda.CUDAGraph()
             with torch.cuda.graph(g_all):
                 fwd_bwd()
-                opt.step()
+                opt_step()
             step = g_all.replay
         elif not args.split_graph and torch.distributed.get_backend() == "nccl":
             # RCCL collectives are capturable: the whole step, all-reduce included, replays as ONE graph (no host
@@ -508,7 +514,7 @@ def main():
                 with torch.cuda.graph(g_all):
                     fwd_bwd()
                     reduce_grads()
-                    opt.step()
+                    opt_step()
                 g_all.replay()
                 torch.cuda.synchronize()
                 step = g_all.replay
@@ -523,7 +529,7 @@ def main():
             with torch.cuda.graph(g_fb):
                 fwd_bwd()
             with torch.cuda.graph(g_opt, pool=g_fb.pool()):
-                opt.step()
+                opt_step()
             graph_mode = "two hipGraphs around an eager all-reduce"
 
             def step():

@@ -287,23 +287,43 @@ extern "C" int emb_counter_add(uint64_t* counter, uint64_t inc, emb_stream_t str
 // table travels BY VALUE in the kernel argument (baked into a hipGraph node at capture time, rebuilt for free
 // on every eager call) and is first copied to LDS, so that it is never indexed dynamically in the kernarg
 // segment (see the hipcc note in embrace_bwd.hip).
+#include <cstring>
 #include <mutex>
 #include <unordered_map>
+#include "reduce.h"
 namespace emb {
+int launch_jobs_f32(const ReduceJob* jobs, int n, hipStream_t s);   // reduce.hip
+int launch_jobs_f64(const ReduceJob* jobs, int n, hipStream_t s);
 constexpr int kMaxTensors = 40;
-constexpr int kChunk = 1024;   // elements per block
+constexpr int kChunk = 1024;   // elements per block (of a tensor whose gradient is a plain tensor)
+constexpr int kMaxSrc = 12;    // queued slab reductions one launch can take over (reduce.h)
+// gradient of a tensor = sum over S slices of a slab (the backward kernels' partial sums, reduce.h) instead of a reduced tensor
+struct SlabSrc {
+  const void* in;
+  long long per;
+  int S, kind, lanes;          // lanes (power of two <= 16) threads share one element's slices
+  int iv[9];
+};
 template <typename P> struct MultiArgs {
   P* p[kMaxTensors];
-  const P* g[kMaxTensors];
+  P* g[kMaxTensors];            // gradient tensor: read (plain) or WRITTEN (slab-sourced: the summed gradient is kept there)
   P* m[kMaxTensors];
   P* v[kMaxTensors];
   __bf16* sh[kMaxTensors];
   __bf16* flip[kMaxTensors];     // conv weights: tap-flipped packed copy (nullable)
-  int pk_k[kMaxTensors], pk_cin[kMaxTensors], pk_cinpad[kMaxTensors], pk_cout[kMaxTensors];   // pk_k == 0: plain shadow
-  long long n[kMaxTensors];
-  long long blk_end[kMaxTensors];
-  long long count;
+  short pk_k[kMaxTensors], pk_cin[kMaxTensors], pk_cinpad[kMaxTensors], pk_cout[kMaxTensors];   // pk_k == 0: plain shadow
+  signed char src[kMaxTensors], which[kMaxTensors];   // src < 0: plain gradient; else index into slab[] and the job's output
+  int n[kMaxTensors];
+  int blk_end[kMaxTensors];
+  SlabSrc slab[kMaxSrc];
+  // queued statistics sums (head.hip: loss, confusion counts) ride along as the last blocks of the launch
+  SlabSrc stats[2];
+  float* stats_loss[2];
+  long long* stats_conf[2];
+  int nstats;
+  int count;
 };
+static_assert(sizeof(MultiArgs<float>) + 128 <= 4096, "kernel argument block");
 enum { OPT_ADAM = 0, OPT_RMSPROP = 1, OPT_NADAM = 2 };
 struct Hyper {
   double lr, b1, b2, eps, wd, alpha, sdecay;
@@ -315,22 +335,44 @@ struct Hyper {
 template <typename P, int OPT>
 __global__ __launch_bounds__(256) void multi_opt_kernel(const MultiArgs<P> args, const Hyper h) {
   __shared__ MultiArgs<P> a;
+  __shared__ P red[256];             // lane partial sums of slab-sourced gradients
   {
-    const unsigned long long* src = reinterpret_cast<const unsigned long long*>(&args);
-    unsigned long long* dst = reinterpret_cast<unsigned long long*>(&a);
-    for (int i = threadIdx.x; i < (int)(sizeof(MultiArgs<P>) / 8); i += 256) dst[i] = src[i];
+    const unsigned* src = reinterpret_cast<const unsigned*>(&args);
+    unsigned* dst = reinterpret_cast<unsigned*>(&a);
+    for (int i = threadIdx.x; i < (int)(sizeof(MultiArgs<P>) / 4); i += 256) dst[i] = src[i];
   }
   __syncthreads();
+  const int last_blk = a.blk_end[a.count - 1];
+  if ((int)blockIdx.x >= last_blk) {     // statistics sums: one block per job, slices split over the 256 threads
+    const int k = (int)blockIdx.x - last_blk;
+    const SlabSrc& sj = a.stats[k];
+    const P* in = (const P*)sj.in;
+    const int q = threadIdx.x & 7, sl = threadIdx.x >> 3;       // per == 8 values per slice (head.hip)
+    P acc = 0;
+    for (int s = sl; s < sj.S; s += 32) acc += in[(long)s * sj.per + q];
+    red[threadIdx.x] = acc;
+    __syncthreads();
+    if (threadIdx.x < 8) {
+      P sum = 0;
+      for (int i = 0; i < 32; ++i) sum += red[i * 8 + threadIdx.x];
+      if (threadIdx.x == 0) a.stats_loss[k][0] = (float)sum;
+      else if (threadIdx.x <= 4 && a.stats_conf[k] != nullptr) a.stats_conf[k][threadIdx.x - 1] = (long long)(sum + (P)0.5);
+    }
+    return;
+  }
   int t = 0;
-  while (t < (int)a.count - 1 && (long long)blockIdx.x >= a.blk_end[t]) ++t;
-  const long long first_blk = t == 0 ? 0 : a.blk_end[t - 1];
-  const long long base = ((long long)blockIdx.x - first_blk) * kChunk;
+  while (t < a.count - 1 && (int)blockIdx.x >= a.blk_end[t]) ++t;
+  const int first_blk = t == 0 ? 0 : a.blk_end[t - 1];
   P* p = a.p[t];
-  const P* g = a.g[t];
+  P* g = a.g[t];
   P* m = a.m[t];
   P* v = a.v[t];
   __bf16* sh = a.sh[t];
-  const long long n = a.n[t];
+  const int n = a.n[t];
+  const int si = a.src[t];
+  const int lanes = si < 0 ? 1 : a.slab[si].lanes;
+  const int epp = 256 / lanes;                                   // elements per pass
+  const long base = (long)((int)blockIdx.x - first_blk) * (kChunk / lanes);
   const uint64_t step = h.step_val + (h.step_dev ? *h.step_dev : 0);
   const double td = (double)step;
   P c1 = 0, c2 = 0, bc2s = 1;
@@ -348,21 +390,46 @@ __global__ __launch_bounds__(256) void multi_opt_kernel(const MultiArgs<P> args,
   }
   const P pb1 = (P)h.b1, pb2 = (P)h.b2, omb1 = (P)(1.0 - h.b1), omb2 = (P)(1.0 - h.b2), pwd = (P)h.wd, peps = (P)h.eps;
   const P pa = (P)h.alpha, oma = (P)(1.0 - h.alpha), plr = (P)h.lr;
+  const int qi = threadIdx.x % epp, sl = threadIdx.x / epp;
 #pragma unroll
   for (int u = 0; u < kChunk / 256; ++u) {
-    const long long i = base + u * 256 + threadIdx.x;
-    if (i >= n) break;
+    const long i = base + (long)u * epp + qi;
+    P graw = 0;
+    if (si < 0) {
+      if (i < n) graw = g[i];
+    } else {                       // sum this element's slices: lane sl takes slices sl, sl + lanes, ...; lanes meet in lane order
+      const SlabSrc& sj = a.slab[si];
+      if (i < n) {
+        const P* in = (const P*)sj.in + reduce_slab_index(sj.kind, sj.iv, a.which[t], i);
+        P acc = 0;
+#pragma unroll 8
+        for (int s = sl; s < sj.S; s += lanes) acc += in[(long)s * sj.per];
+        graw = acc;
+      }
+      if (lanes > 1) {             // (block-uniform)
+        __syncthreads();
+        red[sl * epp + qi] = graw;
+        __syncthreads();
+        if (sl == 0) {
+          P sum = 0;
+          for (int k = 0; k < lanes; ++k) sum += red[k * epp + qi];
+          graw = sum;
+        }
+      }
+      if (sl == 0 && i < n) g[i] = graw;      // the parameter's .grad holds the summed gradient, as after a reduction launch
+    }
+    if (sl != 0 || i >= n) continue;
     P pi = p[i];
-    const P gi = g[i] + pwd * pi;
+    const P gi = graw + pwd * pi;
     if (OPT == OPT_ADAM) {
       const P mi = m[i] + (gi - m[i]) * omb1;
       const P vi = v[i] * pb2 + gi * gi * omb2;
       pi -= c1 * (mi / (sqrt(vi) / bc2s + peps));
       m[i] = mi; v[i] = vi;
     } else if (OPT == OPT_RMSPROP) {
-      const P si = v[i] * pa + gi * gi * oma;
-      pi -= plr * (gi / (sqrt(si) + peps));
-      v[i] = si;
+      const P si_ = v[i] * pa + gi * gi * oma;
+      pi -= plr * (gi / (sqrt(si_) + peps));
+      v[i] = si_;
     } else {
       const P mi = m[i] * pb1 + gi * omb1;
       const P vi = v[i] * pb2 + gi * gi * omb2;
@@ -406,32 +473,76 @@ static int multi_launch(void* const* params, const void* const* grads, void* con
   for (int off = 0; off < ntensors; off += kMaxTensors) {
     const int cnt = ntensors - off < kMaxTensors ? ntensors - off : kMaxTensors;
     MultiArgs<P> a;
+    memset(&a, 0, sizeof(a));
     long long blocks = 0;
+    int nsrc = 0;
     for (int i = 0; i < kMaxTensors; ++i) {
       const int j = off + (i < cnt ? i : 0);
       a.p[i] = (P*)params[j];
-      a.g[i] = (const P*)grads[j];
+      a.g[i] = (P*)const_cast<void*>(grads[j]);
       a.m[i] = s1 ? (P*)s1[j] : nullptr;
       a.v[i] = s2 ? (P*)s2[j] : nullptr;
       a.sh[i] = shadows ? (__bf16*)shadows[j] : nullptr;
       a.flip[i] = nullptr;
       a.pk_k[i] = a.pk_cin[i] = a.pk_cinpad[i] = a.pk_cout[i] = 0;
-      if (sizeof(P) == 4 && i < cnt) {
-        std::lock_guard<std::mutex> lk(pack_mutex());
-        auto it = pack_table().find(params[j]);
-        if (it != pack_table().end() && (int64_t)it->second.Cout * it->second.Cin * it->second.k == sizes[j]) {
-          a.sh[i] = (__bf16*)it->second.wpack;
-          a.flip[i] = (__bf16*)it->second.wflip;
-          a.pk_k[i] = it->second.k; a.pk_cin[i] = it->second.Cin; a.pk_cinpad[i] = it->second.cin_pad; a.pk_cout[i] = it->second.Cout;
+      a.src[i] = -1;
+      a.which[i] = 0;
+      int per_blk = kChunk;
+      if (i < cnt) {
+        if (sizes[j] >= (1ll << 31)) { set_error("optimizer step: tensor of %lld elements", (long long)sizes[j]); return EMB_ERR_ARG; }
+        if (sizeof(P) == 4) {
+          std::lock_guard<std::mutex> lk(pack_mutex());
+          auto it = pack_table().find(params[j]);
+          if (it != pack_table().end() && (int64_t)it->second.Cout * it->second.Cin * it->second.k == sizes[j] &&
+              it->second.cin_pad < 32768 && it->second.Cout < 32768) {
+            a.sh[i] = (__bf16*)it->second.wpack;
+            a.flip[i] = (__bf16*)it->second.wflip;
+            a.pk_k[i] = (short)it->second.k; a.pk_cin[i] = (short)it->second.Cin; a.pk_cinpad[i] = (short)it->second.cin_pad;
+            a.pk_cout[i] = (short)it->second.Cout;
+          }
+        }
+        // a queued slab reduction that would have produced this gradient: sum its slices here instead (reduce.h)
+        ReduceClaim cl;
+        if (nsrc < kMaxSrc + 1 && reduce_claim(grads[j], sizeof(P) == 8, &cl)) {
+          int k = -1;
+          for (int q = 0; q < nsrc; ++q)
+            if (a.slab[q].in == cl.job.in && a.slab[q].per == cl.job.per) k = q;
+          if (k < 0 && nsrc < kMaxSrc) {
+            k = nsrc++;
+            a.slab[k].in = cl.job.in; a.slab[k].per = cl.job.per; a.slab[k].S = cl.job.S; a.slab[k].kind = cl.job.kind;
+            for (int q = 0; q < 9; ++q) a.slab[k].iv[q] = cl.job.iv[q];
+            int lanes = 1;
+            while (lanes < 16 && lanes * 4 < cl.job.S) lanes *= 2;
+            a.slab[k].lanes = lanes;
+          }
+          if (k >= 0) {
+            a.src[i] = (signed char)k;
+            a.which[i] = (signed char)cl.which;
+            per_blk = kChunk / a.slab[k].lanes;
+          } else {                       // table full: put the claim back by running that one reduction the classic way
+            ReduceJob one = cl.job;
+            for (int q = 0; q < 8; ++q) if (q != cl.which) one.out[q] = nullptr;
+            const int rc = sizeof(P) == 8 ? launch_jobs_f64(&one, 1, s) : launch_jobs_f32(&one, 1, s);
+            if (rc != EMB_OK) return rc;
+          }
         }
       }
-      a.n[i] = i < cnt ? sizes[j] : 0;
-      if (i < cnt) blocks += (sizes[j] + kChunk - 1) / kChunk;
-      a.blk_end[i] = blocks;
+      a.n[i] = i < cnt ? (int)sizes[j] : 0;
+      if (i < cnt) blocks += (sizes[j] + per_blk - 1) / per_blk;
+      a.blk_end[i] = (int)blocks;
     }
     a.count = cnt;
-    if (blocks == 0) continue;
-    multi_opt_kernel<P, OPT><<<(int)blocks, 256, 0, s>>>(a, h);
+    a.nstats = 0;
+    ReduceJob sj;
+    while (a.nstats < 2 && off + cnt >= ntensors && reduce_claim_stats(sizeof(P) == 8, &sj)) {   // (last chunk of the call only)
+      SlabSrc& d = a.stats[a.nstats];
+      d.in = sj.in; d.per = sj.per; d.S = sj.S; d.kind = sj.kind; d.lanes = 1;
+      a.stats_loss[a.nstats] = (float*)sj.out[0];
+      a.stats_conf[a.nstats] = (long long*)sj.out[1];
+      ++a.nstats;
+    }
+    if (blocks == 0 && a.nstats == 0) continue;
+    multi_opt_kernel<P, OPT><<<(int)blocks + a.nstats, 256, 0, s>>>(a, h);
     EMB_CHECK_LAUNCH();
   }
   return EMB_OK;

@@ -21,4 +21,35 @@ struct ReduceJob {
 // immediate mode: launches on `s`; deferred mode: queued until emb_reduce_flush().  is_double selects P.
 int reduce_submit(const ReduceJob& job, bool is_double, hipStream_t s);
 
+// Queued jobs as seen by the multi-tensor optimizer launch (loss_optim.hip), which sums the slices of a gradient itself
+// instead of reading the reduced tensor: `reduce_claim` looks for a queued job with an output == `grad`, returns its
+// descriptor and which output it is, and clears that output in the queue (a job whose outputs are all claimed leaves it).
+// `reduce_claim_stats` hands out queued RJ_HEAD_STATS jobs (loss / confusion sums: run as extra blocks of the same launch).
+struct ReduceClaim {
+  ReduceJob job;
+  int which;         // index into job.out
+};
+bool reduce_claim(const void* grad, bool is_double, ReduceClaim* out);
+bool reduce_claim_stats(bool is_double, ReduceJob* out);
+
+// where element i of output `which` of a job lives inside one slice (the inverse of the scatter in reduce.hip)
+__host__ __device__ inline long reduce_slab_index(int kind, const int* iv, int which, long i) {
+  if (kind == RJ_LINEAR) {
+    const int N = iv[0], pitch = iv[1] > 0 ? iv[1] : N + 1;
+    return which == 0 ? (i / N) * pitch + i % N : i * pitch + N;
+  }
+  if (kind == RJ_CONV) {      // slab row = [k*cin_pad tap-major columns | bias]; dW in torch layout [Cout][Cin][k]
+    const int Cin = iv[0], cin_pad = iv[1], k = iv[2], KK = k * cin_pad;
+    if (which == 1) return i * (KK + 1) + KK;
+    const long o = i / ((long)Cin * k);
+    const int rem = (int)(i - o * Cin * k), ci = rem / k, tap = rem - ci * k;
+    return o * (KK + 1) + (long)tap * cin_pad + ci;
+  }
+  // RJ_MLP: per layer [N*K weights | N biases]; outputs 0..3 = dW_l, 4..7 = db_l
+  const int l = which & 3;
+  long off = 0;
+  for (int t = 0; t < l; ++t) off += (long)iv[1 + t] * iv[5 + t] + iv[1 + t];
+  return which < 4 ? off + i : off + (long)iv[1 + l] * iv[5 + l] + i;
+}
+
 }  // namespace emb

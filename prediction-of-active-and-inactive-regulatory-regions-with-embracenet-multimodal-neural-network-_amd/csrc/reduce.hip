@@ -21,14 +21,14 @@ template <typename P> __device__ __forceinline__ void reduce_write(const ReduceJ
     const int N = j.iv[0], pitch = j.iv[1] > 0 ? j.iv[1] : N + 1;   // slab row = [N values | bias | padding up to pitch]
     const long m = q / pitch;
     const int n = (int)(q - m * pitch);
-    if (n == N) ((P*)j.out[1])[m] = t;
-    else if (n < N) ((P*)j.out[0])[m * N + n] = t;
+    if (n == N) { if (j.out[1]) ((P*)j.out[1])[m] = t; }
+    else if (n < N && j.out[0]) ((P*)j.out[0])[m * N + n] = t;
   } else if (j.kind == RJ_CONV) {   // slab row = [k*cin_pad tap-major columns | bias]; dW in torch layout [Cout][Cin][k]
     const int Cin = j.iv[0], cin_pad = j.iv[1], k = j.iv[2], KK = k * cin_pad;
     const int o = (int)(q / (KK + 1)), col = (int)(q - (long)o * (KK + 1));
     const int tap = col / cin_pad, ci = col - tap * cin_pad;
-    if (col == KK) ((P*)j.out[1])[o] = t;
-    else if (ci < Cin) ((P*)j.out[0])[((long)o * Cin + ci) * k + tap] = t;
+    if (col == KK) { if (j.out[1]) ((P*)j.out[1])[o] = t; }
+    else if (ci < Cin && j.out[0]) ((P*)j.out[0])[((long)o * Cin + ci) * k + tap] = t;
   } else if (j.kind == RJ_HEAD_STATS) {   // head.hip: [loss share, tp, pp, positives, rows, -, -, -]; counts are small exact integers
     if (q == 0) ((float*)j.out[0])[0] = (float)t;
     else if (q <= 4 && j.out[1] != nullptr) ((long long*)j.out[1])[q - 1] = (long long)(t + (P)0.5);
@@ -39,9 +39,9 @@ template <typename P> __device__ __forceinline__ void reduce_write(const ReduceJ
     for (int l = 0; l < 4; ++l) {
       if (l < L) {
         const long nw = (long)j.iv[1 + l] * j.iv[5 + l];
-        if (off < nw) { ((P*)j.out[l])[off] = t; return; }
+        if (off < nw) { if (j.out[l]) ((P*)j.out[l])[off] = t; return; }
         off -= nw;
-        if (off < j.iv[1 + l]) { ((P*)j.out[4 + l])[off] = t; return; }
+        if (off < j.iv[1 + l]) { if (j.out[4 + l]) ((P*)j.out[4 + l])[off] = t; return; }
         off -= j.iv[1 + l];
       }
     }
@@ -132,6 +132,42 @@ template <typename P> static int launch_jobs(const ReduceJob* jobs, int n, hipSt
   }
   return EMB_OK;
 }
+
+static int job_outputs(const ReduceJob& j) { return j.kind == RJ_MLP ? 8 : 2; }
+
+bool reduce_claim(const void* grad, bool is_double, ReduceClaim* out) {
+  if (grad == nullptr) return false;
+  std::vector<ReduceJob>& v = is_double ? pending().f64 : pending().f32;
+  for (size_t i = 0; i < v.size(); ++i) {
+    if (v[i].kind == RJ_HEAD_STATS) continue;
+    const int no = job_outputs(v[i]);
+    for (int k = 0; k < no; ++k) {
+      if (v[i].out[k] != grad) continue;
+      out->job = v[i];
+      out->which = k;
+      v[i].out[k] = nullptr;
+      bool any = false;
+      for (int t = 0; t < no; ++t) any = any || v[i].out[t] != nullptr;
+      if (!any) v.erase(v.begin() + (long)i);
+      return true;
+    }
+  }
+  return false;
+}
+
+bool reduce_claim_stats(bool is_double, ReduceJob* out) {
+  std::vector<ReduceJob>& v = is_double ? pending().f64 : pending().f32;
+  for (size_t i = 0; i < v.size(); ++i)
+    if (v[i].kind == RJ_HEAD_STATS) {
+      *out = v[i];
+      v.erase(v.begin() + (long)i);
+      return true;
+    }
+  return false;
+}
+
+int launch_jobs_f32(const ReduceJob* jobs, int n, hipStream_t s) { return launch_jobs<float>(jobs, n, s); }
+int launch_jobs_f64(const ReduceJob* jobs, int n, hipStream_t s) { return launch_jobs<double>(jobs, n, s); }
 
 int reduce_submit(const ReduceJob& job, bool is_double, hipStream_t s) {
   if (job.per <= 0 || job.S <= 0) return EMB_OK;

@@ -106,6 +106,7 @@ class StepRunner:
         self.graph = GRAPH_STEPS if graph is None else bool(graph)
         self._graphs = {}
         self.fuse_loss = True
+        self.consume_slabs = True      # let this package's optimizers sum the backward's gradient slabs in their own launch
         on_gpu_ = torch.device(device).type == "cuda"
         # data parallel on the GPU: every gradient is a view of one of two flat buffers the backward kernels write directly;
         # the first bucket (post stack, head, docking) is all-reduced while the pre-networks' backward still runs
@@ -290,6 +291,10 @@ class StepRunner:
                 F_.reduce_flush()
                 self.flat.allreduce_early()
             F_.set_after_embrace_backward(early)
+        # single process with one of this package's optimizers: its launch sums the queued slabs itself (no reduction launch);
+        # otherwise (torch optimizers, data parallel: the all-reduce needs finished gradients) they are flushed after backward
+        consume = (deferred and self.consume_slabs and self.flat is None and D.world_size() == 1
+                   and isinstance(self.optimizer, fused_optim._Fused))
         try:
             # the loss is the root of the graph: d loss / d logits comes from the loss kernel (or, fused, is already inside
             # the head's node, which ignores what it is handed)
@@ -298,7 +303,8 @@ class StepRunner:
             F_.set_after_embrace_backward(None)
             if deferred:
                 F_.reduce_defer(False)
-                F_.reduce_flush()       # ... and run in one launch here
+                if not consume:
+                    F_.reduce_flush()   # ... and run in one launch here
         if self._redundant:
             self._drop_redundant((table.loss[slots_before:table.n], table.counts[slots_before:table.n]))
         if self.flat is not None:
@@ -312,6 +318,8 @@ class StepRunner:
         finally:
             if self.opt_tick is not None:
                 self.optimizer.external_tick = False
+            if consume:
+                F_.reduce_flush()       # whatever the optimizer launch did not take (normally nothing: no launch)
         return output, loss
 
     def _eval_step_eager(self, x_1, x_2, target, table):
@@ -502,41 +510,77 @@ def path_augmentation(augmentation):
     return '_augmentation' if augmentation else ''
 
 
-class Kfold_CV_Multimodal:
-    """k-fold cross-validation driver (training_models_multimodal.py:475-798): per fold, tune on a
-    train/validation split, re-initialise the best model and train/test it.  Data handling is the
-    reference's own ``BIOINF_tesi.data_pipe`` (out of scope of this engine, imported when called)."""
+def _rows(a):
+    """pandas objects / lists of them / arrays -> numpy rows (row order = concatenation order)"""
+    if isinstance(a, (list, tuple)):
+        return np.concatenate([_rows(x) for x in a])
+    return a.to_numpy() if hasattr(a, "to_numpy") else np.asarray(a)
 
-    def __init__(self):
+
+def encode_sequences(seq):
+    """Nucleotide windows -> uint8 base codes [N, L] (a, c, g, t = 0..3 -- the channel order of the reference's one-hot
+    encoder, data_pipe/utils.py:269-276 -- anything else, e.g. 'n', = 4: an all-zero column).  Accepts strings, one-hot
+    [N, 4, L] arrays or ready-made codes."""
+    a = _rows(seq)
+    if a.dtype == np.uint8 and a.ndim == 2:
+        return a
+    if a.ndim == 3:
+        return F_.pack_onehot(torch.as_tensor(a)).cpu().numpy()
+    strings = [str(x[0] if isinstance(x, (np.ndarray, list, tuple)) else x).lower() for x in a]
+    lut = np.full(256, 4, dtype=np.uint8)
+    for i, ch in enumerate("acgt"):
+        lut[ord(ch)] = i
+    width = max(len(t) for t in strings)
+    out = np.full((len(strings), width), 4, dtype=np.uint8)
+    for r, t in enumerate(strings):
+        out[r, :len(t)] = lut[np.frombuffer(t.encode("ascii", "replace"), dtype=np.uint8)]
+    return out
+
+
+class Kfold_CV_Multimodal:
+    """k-fold cross-validation driver with the reference's call surface (training_models_multimodal.py:475-798): per fold,
+    tune on a train / validation split, re-initialise the best model and train / test it.
+
+    What is built here is the DEVICE side: every split is staged once in HBM and batched by row gathers
+    (data.device_loaders -- the balanced training sampler and the shuffled test loader reproduce the reference's batch
+    index lists bit for bit, fixture G11).  The reference's table ETL around it (SMOTE / MICE re-balancing and
+    augmentation, BIOINF_tesi/data_pipe) is out of scope: pass `rebalance=callable(X, y, sequence,
+    threshold) -> (X, y)` to apply it; without one, a training split the reference would have re-balanced raises instead
+    of silently training on different data."""
+
+    def __init__(self, rebalance=None):
         self.scores_dict = defaultdict(dd)
         self.scores_dict['final_test_AUPRC_scores'] = []
         self.scores_dict['final_train_AUPRC_scores'] = []
         self.model_, self.optimizer = [], []
         self.best_params = defaultdict(dict)
+        self.rebalance = rebalance
 
-    def build_dataloader_forCV(self, X, y, sequence, batch_size=100, training=True, augmentation=False):
-        import pandas as pd
-        from torch.utils.data import DataLoader
-        from BIOINF_tesi.data_pipe.dataprepare import BalancePos_BatchSampler, Dataset_Wrap
-        from BIOINF_tesi.data_pipe.utils import data_augmentation, data_rebalancing, get_imbalance
-        if isinstance(X, list):
-            for x_ in X:
-                x_.reset_index(drop=True, inplace=True)
-            for y_ in y:
-                y_.reset_index(drop=True, inplace=True)
-            X, y = pd.concat(list(X)), pd.concat(list(y))
-        else:
-            X.reset_index(drop=True, inplace=True), y.reset_index(drop=True, inplace=True)
+    def build_dataloaders_forCV(self, X_1, X_2, y, batch_size=100, training=True, augmentation=False):
+        """{'FFNN': loader, 'CNN': loader} over one device-resident split (the reference builds the two loaders separately
+        with one sampler seed, :592-616; here they share the staged split and its index lists)."""
+        from . import data
+        y_rows = _rows(y).reshape(-1)
         if training:
-            if augmentation:
-                X, y = data_augmentation(X, y, sequence=sequence, rebalance_threshold=self.rebalance_threshold)
-            elif get_imbalance(y) < self.rebalance_threshold:
-                X, y = data_rebalancing(X, y, sequence=sequence, rebalance_threshold=self.rebalance_threshold)
-        wrap = Dataset_Wrap(X, y, sequence=sequence)
+            pos = float((y_rows == 1).mean()) if len(y_rows) else 0.0
+            needs = augmentation or min(pos, 1.0 - pos) < self.rebalance_threshold      # get_imbalance(y) < threshold (:600-603)
+            if needs:
+                if self.rebalance is None:
+                    raise NotImplementedError(
+                        "this training split is below the rebalance threshold (or augmentation was requested): the reference "
+                        "re-balances it with SMOTE/MICE (data_pipe.utils.data_rebalancing / data_augmentation), which is outside "
+                        "this engine -- construct Kfold_CV_Multimodal(rebalance=...) with that step")
+                X_1, y1 = self.rebalance(X_1, y, False, self.rebalance_threshold)
+                X_2, y = self.rebalance(X_2, y, True, self.rebalance_threshold)
+                y_rows = _rows(y).reshape(-1)
+        x1 = _rows(X_1).astype(np.float64)
+        seq = encode_sequences(X_2)
+        dt = _PRECISIONS[self.precision or DEFAULT_PRECISION]
         if training:
-            return DataLoader(dataset=wrap, batch_sampler=BalancePos_BatchSampler(wrap, batch_size=batch_size))
-        return DataLoader(dataset=wrap, batch_size=batch_size * 2, shuffle=True,
-                          generator=torch.Generator().manual_seed(self.random_state + 30))
+            return data.device_loaders(x1, seq, y_rows, batch_size, self.device, balanced=True, random_state=self.random_state,
+                                       feature_dtype=dt)
+        return data.device_loaders(x1, seq, y_rows, batch_size * 2, self.device, balanced=False,
+                                   random_state=self.random_state + 30, feature_dtype=dt)
 
     def hyper_tuning(self, train_loader, test_loader, num_epochs, cell_line, task, study_name, device, sampler):
         param_search = Param_Search_Multimodal(model=self.model_, train_loader=train_loader, test_loader=test_loader,
@@ -582,28 +626,26 @@ class Kfold_CV_Multimodal:
                                                          random_state=self.random_state)
         _, X_2, _ = data_class.return_index_data_for_cv(cell_line=cell_line, sequence=True, n_folds=n_folds,
                                                         random_state=self.random_state)
+        take = lambda a, idx: a.iloc[idx] if hasattr(a, "iloc") else a[idx]
         for i, (train_index, test_index) in enumerate(kf.split(X_1)):
             self.i = i + 1
             STUDY_NAME = f'{study_name}_{str(self.i)}'
             print(f'>>> ITERATION N. {self.i}')
-            X_train_1, X_test_1 = X_1.iloc[train_index], X_1.iloc[test_index]
-            X_train_2, X_test_2 = X_2.iloc[train_index], X_2.iloc[test_index]
-            y_train, y_test = y.iloc[train_index], y.iloc[test_index]
-            X_train_1, X_val_1, _, _ = train_test_split(X_train_1, y_train, test_size=1 / self.n_folds,
-                                                        random_state=self.random_state, shuffle=True)
-            X_train_2, X_val_2, y_train, y_val = train_test_split(X_train_2, y_train, test_size=1 / self.n_folds,
-                                                                  random_state=self.random_state, shuffle=True)
+            X_train_1, X_test_1 = take(X_1, train_index), take(X_1, test_index)
+            X_train_2, X_test_2 = take(X_2, train_index), take(X_2, test_index)
+            y_train, y_test = take(y, train_index), take(y, test_index)
+            # (:731-741) the same split of the training part for both modalities: one call with both keeps them aligned
+            X_train_1, X_val_1, X_train_2, X_val_2, y_train, y_val = train_test_split(
+                X_train_1, X_train_2, y_train, test_size=1 / self.n_folds, random_state=self.random_state, shuffle=True)
             self.model_ = model
             print('\n===============> HYPERPARAMETERS TUNING')
-            mk = lambda Xa, Xb, yy, tr, aug: {
-                'FFNN': self.build_dataloader_forCV(Xa, yy, sequence=False, batch_size=batch_size, training=tr, augmentation=aug),
-                'CNN': self.build_dataloader_forCV(Xb, yy, sequence=True, batch_size=batch_size, training=tr, augmentation=aug)}
-            self.hyper_tuning(mk(X_train_1, X_train_2, y_train, True, self.augmentation),
-                              mk(X_val_1, X_val_2, y_val, False, False), num_epochs, cell_line, task, STUDY_NAME,
-                              device, sampler)
+            self.hyper_tuning(self.build_dataloaders_forCV(X_train_1, X_train_2, y_train, batch_size, True, self.augmentation),
+                              self.build_dataloaders_forCV(X_val_1, X_val_2, y_val, batch_size, False, False),
+                              num_epochs, cell_line, task, STUDY_NAME, device, sampler)
             print('\n===============> MODEL TESTING')
-            train_loader = mk([X_train_1, X_val_1], [X_train_2, X_val_2], [y_train, y_val], True, self.augmentation)
-            test_loader = mk(X_test_1, X_test_2, y_test, False, False)
+            train_loader = self.build_dataloaders_forCV([X_train_1, X_val_1], [X_train_2, X_val_2], [y_train, y_val], batch_size,
+                                                        True, self.augmentation)
+            test_loader = self.build_dataloaders_forCV(X_test_1, X_test_2, y_test, batch_size, False, False)
             self.model_testing(train_loader, test_loader, num_epochs, test_model_path, device, cell_line, task,
                                checkpoint_path=f'{cell_line}_{model.__name__}{path_augmentation(self.augmentation)}_{task}_{self.i}_test_')
         avg_CV_AUPRC = np.round(sum(self.avg_score) / n_folds, 5)

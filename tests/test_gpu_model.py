@@ -348,6 +348,37 @@ def test_graph_steps_follow_a_changing_learning_rate(ea):
         assert torch.equal(sa[k], sb[k]), k
 
 
+@pytest.mark.parametrize("precision,opt_name", [("float64", "Adam"), ("float32", "Adam"), ("bfloat16", "Nadam"), ("float32", "RMSprop")])
+def test_optimizer_launch_sums_the_gradient_slabs_itself(ea, precision, opt_name):
+    """Single process: the backward kernels' per-slice gradient slabs are summed inside the multi-tensor optimizer launch
+    (no reduction launch; csrc/loss_optim.hip) -- same parameters and the same .grad tensors as with the reduction launch in
+    front of the optimizer, up to the summation order of the slices."""
+    from embracenet_amd import training
+    def run(consume):
+        model, trial, hp, F_in = build(ea, "post2", "slabopt", torch.float64)
+        model = training.prepare_model(model, DEV, precision).set_rng("philox", seed=3)
+        opt = training.make_optimizer(opt_name, model.parameters(), 2e-3, 1e-3)
+        runner = training.StepRunner(model, opt, DEV)
+        runner.consume_slabs = consume
+        table = ea.metrics.StepTable(8, DEV)
+        model.train()
+        cast = torch.float64 if precision == "float64" else torch.float32
+        for k in range(3):
+            a, b, y = model_batch(f"slabopt/{k}", 96, F_in, 0.3)
+            runner.train_step(torch.from_numpy(a).to(cast), torch.from_numpy(b).to(cast), torch.from_numpy(y), table)
+        losses, counts = table.fetch()
+        return (losses, counts, {k: v.detach().double().cpu() for k, v in model.state_dict().items()},
+                {k: p.grad.detach().double().cpu() for k, p in model.named_parameters()})
+    la, ca, sa, ga = run(False)
+    lb, cb, sb, gb = run(True)
+    tol = 1e-11 if precision == "float64" else 3e-5
+    assert np.array_equal(ca, cb) and np.abs(la - lb).max() < 1e-5
+    for k in sa:
+        assert (sa[k] - sb[k]).abs().max().item() <= tol * max(1.0, sa[k].abs().max().item()), k
+    for k in ga:
+        assert (ga[k] - gb[k]).abs().max().item() <= tol * max(1e-3, ga[k].abs().max().item()), ("grad", k)
+
+
 def test_captured_steps_survive_workspace_growth_and_cache_release(ea):
     """A captured step graph has the scratch buffers' addresses baked in.  Larger batches arriving later (the test loader
     runs at twice the train batch, BalancePos batches differ by a row) must not hand those buffers back to the allocator:
@@ -478,3 +509,41 @@ def test_param_search_objective_with_a_fixed_trial(ea, opt_name, tmp_path):
     assert type(saved).__name__ == "EmbraceNetMultimodal"
     for a, b in zip(saved.state_dict().values(), ps.model.state_dict().values()):
         assert torch.equal(a.cpu(), b.cpu())
+
+
+def test_kfold_cv_driver_runs_on_device_loaders(ea, tmp_path, monkeypatch):
+    """Kfold_CV_Multimodal.__call__ (training_models_multimodal.py:645-798) end to end on stubs of the reference's data
+    pipeline object and of the Optuna study: folds, train / validation split, tuning, re-initialised best model, fit, scores.
+    Nothing of the reference is imported."""
+    import pandas as pd
+    from sklearn.model_selection import KFold
+    from embracenet_amd import training
+    hp, F_in = CONFIGS["small"]
+    N = 150
+    X1 = pd.DataFrame(dg.uniform("kf/x1", (N, F_in)))
+    bases = np.array(list("acgt"))[dg.integers("kf/seq", (N, 256), 4)]
+    X2 = pd.DataFrame({"seq": ["".join(r) for r in bases]})
+    y = pd.DataFrame({"y": dg.labels("kf/y", N, 0.35).reshape(-1)})
+
+    class _DataClass:
+        def return_index_data_for_cv(self, cell_line, sequence, n_folds, random_state):
+            return KFold(n_splits=n_folds, shuffle=True, random_state=random_state), (X2 if sequence else X1), y
+
+    class _Pipeline:
+        data_class = _DataClass()
+
+    def fake_run_trial(self):                                    # one "trial" instead of an Optuna study (optuna is not installed)
+        trial = _ObjectiveTrial(dict(hp, optimizer="Adam", lr=1e-3, weight_decay=1e-3), number=0)
+        self.objective(trial)
+        self.best_model = torch.load(f"{self.study_name}0.pt", weights_only=False)
+        self.best_params = dict(optimizer="Adam", lr=1e-3, weight_decay=1e-3)
+    monkeypatch.setattr(training.Param_Search_Multimodal, "run_trial", fake_run_trial)
+    monkeypatch.chdir(tmp_path)
+    cv = training.Kfold_CV_Multimodal()
+    cv(_Pipeline(), "A549", DEV, task="active_E_vs_inactive_E", model=ea.EmbraceNetMultimodal, n_folds=2, num_epochs=2,
+       batch_size=16, study_name=str(tmp_path / "cv"), test_model_path="best", precision="float32")
+    assert len(cv.scores_dict["final_test_AUPRC_scores"]) == 2 and 0.0 <= cv.scores_dict["average_CV_AUPRC"] <= 1.0
+    assert (tmp_path / "models_" / "best.pt").exists()
+    with pytest.raises(NotImplementedError):                     # a split the reference would re-balance: loud, not silent
+        cv.rebalance_threshold = 0.45
+        cv.build_dataloaders_forCV(X1, X2, y, 16, True, False)

@@ -1,8 +1,11 @@
 mkdir -p gpurun_out
-cd /tmp && export TMPDIR=/tmp
-rm -rf /root/repo/gpurun_out/prof_r2a
-rocprofv3 --kernel-trace --stats --output-format csv -d /root/repo/gpurun_out/prof_r2a -- python3 /root/repo/bench.py --steps 60 --warmup 10 --no-extras > /root/repo/gpurun_out/prof_r2a.log 2>&1
-cd /root/repo
-python tools/per_step.py gpurun_out/prof_r2a first_kernel > gpurun_out/prof_r2a_per_step.txt 2>&1
-cat gpurun_out/prof_r2a_per_step.txt
-ls gpurun_out/prof_r2a/*/ | head
+timeout -k 10 1100 python -m pytest tests -x -q -m gpu > gpurun_out/t_all.log 2>&1; rc=$?; tail -15 gpurun_out/t_all.log
+if [ $rc -ne 0 ]; then exit $rc; fi
+timeout -k 10 600 python bench.py > gpurun_out/bench.log 2> gpurun_out/bench.err; tail -3 gpurun_out/bench.err; python - <<'PY'
+import json
+d=json.loads(open('gpurun_out/bench.log').read().strip().splitlines()[-1])
+print({k:d[k] for k in ('value','ms_per_step')})
+print(d['cpu_baseline'])
+print(d['extra'])
+print(d['roofline']['step']['whole_step'])
+PY
