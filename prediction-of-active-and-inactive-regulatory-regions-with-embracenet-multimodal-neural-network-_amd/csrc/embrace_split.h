@@ -64,6 +64,8 @@ __global__ __launch_bounds__(kThreads, 1) void embrace_fwd_split_kernel(
   constexpr int KV = Elem<T>::VEC * 4;           // elements per modality-0 k-block
   extern __shared__ __attribute__((aligned(16))) char smem[];
 
+  EMB_STAMP(2);
+  EMB_STAMP_KIND(0);
   const int tile = xcd_remap(blockIdx.x, ntiles);
   const int row0 = (tile / tiles_n) * TM, col0 = (tile % tiles_n) * TN;
   const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -129,9 +131,11 @@ __global__ __launch_bounds__(kThreads, 1) void embrace_fwd_split_kernel(
     mma_frags<T, MI, NI>(a0, w0, acc0);
   }
 
+  EMB_STAMP(3);
   const RmLane rl = rm_lane(lane);
   for (int it = 0; it < n_my; ++it) {
     wait_chunks_in_flight<G>(min(n_my - it - 1, NSTAGE - 1));   // chunk `it` has landed
+    if (it == 0) EMB_STAMP(4);
     const uint32_t st = ring + (uint32_t)((it % NSTAGE) * STAGE);
     V a[2][MI], b[2][NI];
 #pragma unroll
@@ -146,6 +150,7 @@ __global__ __launch_bounds__(kThreads, 1) void embrace_fwd_split_kernel(
     mma_frags<T, MI, NI>(a[0], b[0], acc1);
     mma_frags<T, MI, NI>(a[1], b[1], acc1);
   }
+  EMB_STAMP(5);
   __syncthreads();                               // every wave is done with its ring
 
   // ---- partial tiles -> LDS (one region per wave and modality)
@@ -161,6 +166,7 @@ __global__ __launch_bounds__(kThreads, 1) void embrace_fwd_split_kernel(
         part[(wave * 2 + 1) * Cfg::SLAB + idx] = acc1[mi][ni][q];
       }
   __syncthreads();
+  EMB_STAMP(6);
 
   // ---- sum in wave order (deterministic), select, bias, ReLU, stores: 4 consecutive columns of one row per thread
   const uint64_t stream = rng_stream(step, EMB_RNG_SELECT);
@@ -214,6 +220,7 @@ __global__ __launch_bounds__(kThreads, 1) void embrace_fwd_split_kernel(
         }
     }
   }
+  EMB_STAMP(8);
 }
 
 template <typename T, int MI, int NI, int NSTAGE>

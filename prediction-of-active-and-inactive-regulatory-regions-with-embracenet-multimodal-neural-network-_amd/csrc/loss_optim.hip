@@ -297,12 +297,16 @@ int launch_jobs_f64(const ReduceJob* jobs, int n, hipStream_t s);
 constexpr int kMaxTensors = 40;
 constexpr int kChunk = 1024;   // elements per block (of a tensor whose gradient is a plain tensor)
 constexpr int kMaxSrc = 12;    // queued slab reductions one launch can take over (reduce.h)
-// gradient of a tensor = sum over S slices of a slab (the backward kernels' partial sums, reduce.h) instead of a reduced tensor
+// Gradients that arrive as S slices of a slab (the backward kernels' partial sums, reduce.h): blocks walk the SLAB in its
+// own element order (coalesced 16-byte reads of every slice, as reduce.hip does), sum the slices in fixed order and update
+// the parameter element the slab element belongs to.
 struct SlabSrc {
   const void* in;
   long long per;
-  int S, kind, lanes;          // lanes (power of two <= 16) threads share one element's slices
+  int S, kind, lanes, vec;     // lanes (power of two <= 16) threads share one element's slices; vec = elements per thread (4 or 1)
+  int blk_end;                 // exclusive end of this job's block range (after the plain tensors' blocks)
   int iv[9];
+  signed char tensor[8];       // job output -> tensor index of this launch (-1: not ours)
 };
 template <typename P> struct MultiArgs {
   P* p[kMaxTensors];
@@ -312,10 +316,10 @@ template <typename P> struct MultiArgs {
   __bf16* sh[kMaxTensors];
   __bf16* flip[kMaxTensors];     // conv weights: tap-flipped packed copy (nullable)
   short pk_k[kMaxTensors], pk_cin[kMaxTensors], pk_cinpad[kMaxTensors], pk_cout[kMaxTensors];   // pk_k == 0: plain shadow
-  signed char src[kMaxTensors], which[kMaxTensors];   // src < 0: plain gradient; else index into slab[] and the job's output
   int n[kMaxTensors];
-  int blk_end[kMaxTensors];
+  int blk_end[kMaxTensors];     // plain-gradient tensors only (a slab-sourced tensor has no blocks of its own)
   SlabSrc slab[kMaxSrc];
+  int nsrc;
   // queued statistics sums (head.hip: loss, confusion counts) ride along as the last blocks of the launch
   SlabSrc stats[2];
   float* stats_loss[2];
@@ -332,122 +336,183 @@ struct Hyper {
   double* m_schedule;
 };
 
+template <typename P> struct OptConst {
+  P c1, c2, bc2s, pb1, pb2, omb1, omb2, pwd, peps, pa, oma, plr;
+};
+
+// update element i of tensor t with the (raw, weight-decay-free) gradient g
+template <typename P, int OPT>
+__device__ __forceinline__ void opt_update(const MultiArgs<P>& a, const OptConst<P>& k, int t, long i, P graw) {
+  P* p = a.p[t];
+  P* m = a.m[t];
+  P* v = a.v[t];
+  P pi = p[i];
+  const P gi = graw + k.pwd * pi;
+  if (OPT == OPT_ADAM) {
+    const P mi = m[i] + (gi - m[i]) * k.omb1;
+    const P vi = v[i] * k.pb2 + gi * gi * k.omb2;
+    pi -= k.c1 * (mi / (sqrt(vi) / k.bc2s + k.peps));
+    m[i] = mi; v[i] = vi;
+  } else if (OPT == OPT_RMSPROP) {
+    const P si = v[i] * k.pa + gi * gi * k.oma;
+    pi -= k.plr * (gi / (sqrt(si) + k.peps));
+    v[i] = si;
+  } else {
+    const P mi = m[i] * k.pb1 + gi * k.omb1;
+    const P vi = v[i] * k.pb2 + gi * gi * k.omb2;
+    const P denom = sqrt(vi) / k.bc2s + k.peps;
+    pi -= k.c1 * (gi / denom);
+    pi -= k.c2 * (mi / denom);
+    m[i] = mi; v[i] = vi;
+  }
+  p[i] = pi;
+  __bf16* sh = a.sh[t];
+  if (sh) {
+    const int kk = a.pk_k[t];
+    if (kk == 0) {
+      sh[i] = (__bf16)(float)pi;
+    } else {   // registered conv weight W[o][ci][j]: keep its packed images current (see emb_conv_pack_register)
+      const int cin = a.pk_cin[t], ii = (int)i, o = ii / (cin * kk), rem = ii - o * cin * kk, ci = rem / kk, j = rem - ci * kk;
+      sh[((long)o * kk + j) * a.pk_cinpad[t] + ci] = (__bf16)(float)pi;
+      if (a.flip[t]) a.flip[t][((long)ci * kk + (kk - 1 - j)) * a.pk_cout[t] + o] = (__bf16)(float)pi;
+    }
+  }
+}
+
+// slab element q of a job -> (output of the job, element of that output); false: padding
+__device__ __forceinline__ bool slab_target(const SlabSrc& j, long q, int* which, long* idx) {
+  if (j.kind == RJ_LINEAR) {
+    const int N = j.iv[0], pitch = j.iv[1] > 0 ? j.iv[1] : N + 1;
+    const long m = q / pitch;
+    const int n = (int)(q - m * pitch);
+    if (n > N) return false;
+    *which = n == N ? 1 : 0;
+    *idx = n == N ? m : m * N + n;
+    return true;
+  }
+  if (j.kind == RJ_CONV) {
+    const int Cin = j.iv[0], cin_pad = j.iv[1], k = j.iv[2], KK = k * cin_pad;
+    const int o = (int)(q / (KK + 1)), col = (int)(q - (long)o * (KK + 1));
+    if (col == KK) { *which = 1; *idx = o; return true; }
+    const int tap = col / cin_pad, ci = col - tap * cin_pad;
+    if (ci >= Cin) return false;
+    *which = 0;
+    *idx = ((long)o * Cin + ci) * k + tap;
+    return true;
+  }
+  long off = q;   // RJ_MLP: per layer [N*K weights | N biases]
+  const int L = j.iv[0];
+#pragma unroll
+  for (int l = 0; l < 4; ++l) {
+    if (l < L) {
+      const long nw = (long)j.iv[1 + l] * j.iv[5 + l];
+      if (off < nw) { *which = l; *idx = off; return true; }
+      off -= nw;
+      if (off < j.iv[1 + l]) { *which = 4 + l; *idx = off; return true; }
+      off -= j.iv[1 + l];
+    }
+  }
+  return false;
+}
+
 template <typename P, int OPT>
 __global__ __launch_bounds__(256) void multi_opt_kernel(const MultiArgs<P> args, const Hyper h) {
   __shared__ MultiArgs<P> a;
-  __shared__ P red[256];             // lane partial sums of slab-sourced gradients
+  __shared__ P red[4][256];          // lane partial sums of slab-sourced gradients
   {
     const unsigned* src = reinterpret_cast<const unsigned*>(&args);
     unsigned* dst = reinterpret_cast<unsigned*>(&a);
     for (int i = threadIdx.x; i < (int)(sizeof(MultiArgs<P>) / 4); i += 256) dst[i] = src[i];
   }
   __syncthreads();
-  const int last_blk = a.blk_end[a.count - 1];
-  if ((int)blockIdx.x >= last_blk) {     // statistics sums: one block per job, slices split over the 256 threads
-    const int k = (int)blockIdx.x - last_blk;
+  const int bid = (int)blockIdx.x;
+  const int plain_end = a.blk_end[a.count - 1];
+  const int slab_end = a.nsrc ? a.slab[a.nsrc - 1].blk_end : plain_end;
+  if (bid >= slab_end) {     // statistics sums: one block per job, slices split over the 256 threads
+    const int k = bid - slab_end;
     const SlabSrc& sj = a.stats[k];
     const P* in = (const P*)sj.in;
     const int q = threadIdx.x & 7, sl = threadIdx.x >> 3;       // per == 8 values per slice (head.hip)
     P acc = 0;
     for (int s = sl; s < sj.S; s += 32) acc += in[(long)s * sj.per + q];
-    red[threadIdx.x] = acc;
+    red[0][threadIdx.x] = acc;
     __syncthreads();
     if (threadIdx.x < 8) {
       P sum = 0;
-      for (int i = 0; i < 32; ++i) sum += red[i * 8 + threadIdx.x];
+      for (int i = 0; i < 32; ++i) sum += red[0][i * 8 + threadIdx.x];
       if (threadIdx.x == 0) a.stats_loss[k][0] = (float)sum;
       else if (threadIdx.x <= 4 && a.stats_conf[k] != nullptr) a.stats_conf[k][threadIdx.x - 1] = (long long)(sum + (P)0.5);
     }
     return;
   }
-  int t = 0;
-  while (t < a.count - 1 && (int)blockIdx.x >= a.blk_end[t]) ++t;
-  const int first_blk = t == 0 ? 0 : a.blk_end[t - 1];
-  P* p = a.p[t];
-  P* g = a.g[t];
-  P* m = a.m[t];
-  P* v = a.v[t];
-  __bf16* sh = a.sh[t];
-  const int n = a.n[t];
-  const int si = a.src[t];
-  const int lanes = si < 0 ? 1 : a.slab[si].lanes;
-  const int epp = 256 / lanes;                                   // elements per pass
-  const long base = (long)((int)blockIdx.x - first_blk) * (kChunk / lanes);
   const uint64_t step = h.step_val + (h.step_dev ? *h.step_dev : 0);
   const double td = (double)step;
-  P c1 = 0, c2 = 0, bc2s = 1;
+  OptConst<P> kc;
+  kc.c1 = 0; kc.c2 = 0; kc.bc2s = 1;
   if (OPT == OPT_ADAM) {
-    c1 = (P)(h.lr / (1.0 - pow(h.b1, td)));
-    bc2s = (P)sqrt(1.0 - pow(h.b2, td));
+    kc.c1 = (P)(h.lr / (1.0 - pow(h.b1, td)));
+    kc.bc2s = (P)sqrt(1.0 - pow(h.b2, td));
   } else if (OPT == OPT_NADAM) {
     const double mu_t = h.b1 * (1.0 - 0.5 * pow(0.96, td * h.sdecay));
     const double mu_n = h.b1 * (1.0 - 0.5 * pow(0.96, (td + 1.0) * h.sdecay));
     const double ms_new = h.m_schedule[(step + 1) & 1] * mu_t, ms_next = ms_new * mu_n;
-    c1 = (P)(h.lr * (1.0 - mu_t) / (1.0 - ms_new));
-    c2 = (P)(h.lr * mu_n / (1.0 - ms_next));
-    bc2s = (P)sqrt(1.0 - pow(h.b2, td));
+    kc.c1 = (P)(h.lr * (1.0 - mu_t) / (1.0 - ms_new));
+    kc.c2 = (P)(h.lr * mu_n / (1.0 - ms_next));
+    kc.bc2s = (P)sqrt(1.0 - pow(h.b2, td));
     if (blockIdx.x == 0 && threadIdx.x == 0) h.m_schedule[step & 1] = ms_new;
   }
-  const P pb1 = (P)h.b1, pb2 = (P)h.b2, omb1 = (P)(1.0 - h.b1), omb2 = (P)(1.0 - h.b2), pwd = (P)h.wd, peps = (P)h.eps;
-  const P pa = (P)h.alpha, oma = (P)(1.0 - h.alpha), plr = (P)h.lr;
-  const int qi = threadIdx.x % epp, sl = threadIdx.x / epp;
+  kc.pb1 = (P)h.b1; kc.pb2 = (P)h.b2; kc.omb1 = (P)(1.0 - h.b1); kc.omb2 = (P)(1.0 - h.b2); kc.pwd = (P)h.wd; kc.peps = (P)h.eps;
+  kc.pa = (P)h.alpha; kc.oma = (P)(1.0 - h.alpha); kc.plr = (P)h.lr;
+
+  if (bid < plain_end) {      // a tensor whose gradient is a plain tensor
+    int t = 0;
+    while (t < a.count - 1 && bid >= a.blk_end[t]) ++t;
+    const long base = (long)(bid - (t == 0 ? 0 : a.blk_end[t - 1])) * kChunk;
+    const P* g = a.g[t];
+    const int n = a.n[t];
 #pragma unroll
-  for (int u = 0; u < kChunk / 256; ++u) {
-    const long i = base + (long)u * epp + qi;
-    P graw = 0;
-    if (si < 0) {
-      if (i < n) graw = g[i];
-    } else {                       // sum this element's slices: lane sl takes slices sl, sl + lanes, ...; lanes meet in lane order
-      const SlabSrc& sj = a.slab[si];
-      if (i < n) {
-        const P* in = (const P*)sj.in + reduce_slab_index(sj.kind, sj.iv, a.which[t], i);
-        P acc = 0;
+    for (int u = 0; u < kChunk / 256; ++u) {
+      const long i = base + u * 256 + threadIdx.x;
+      if (i < n) opt_update<P, OPT>(a, kc, t, i, g[i]);
+    }
+    return;
+  }
+  // a queued slab reduction: lane sl of an element sums slices sl, sl + lanes, ...; the lane sums meet in lane order
+  int k = 0;
+  while (k < a.nsrc - 1 && bid >= a.slab[k].blk_end) ++k;
+  const SlabSrc& sj = a.slab[k];
+  const int jb = bid - (k == 0 ? plain_end : a.slab[k - 1].blk_end);
+  const int lanes = sj.lanes, qpb = 256 / lanes, qi = threadIdx.x % qpb, sl = threadIdx.x / qpb;
+  const long per = sj.per;
+  const P* in = (const P*)sj.in;
+  P acc[4] = {0, 0, 0, 0};
+  const long q0 = ((long)jb * qpb + qi) * sj.vec;
+  if (q0 < per) {
+    if (sj.vec == 4) {
+      typedef P P4 __attribute__((ext_vector_type(4)));
+      P4 s4 = {0, 0, 0, 0};
 #pragma unroll 8
-        for (int s = sl; s < sj.S; s += lanes) acc += in[(long)s * sj.per];
-        graw = acc;
-      }
-      if (lanes > 1) {             // (block-uniform)
-        __syncthreads();
-        red[sl * epp + qi] = graw;
-        __syncthreads();
-        if (sl == 0) {
-          P sum = 0;
-          for (int k = 0; k < lanes; ++k) sum += red[k * epp + qi];
-          graw = sum;
-        }
-      }
-      if (sl == 0 && i < n) g[i] = graw;      // the parameter's .grad holds the summed gradient, as after a reduction launch
-    }
-    if (sl != 0 || i >= n) continue;
-    P pi = p[i];
-    const P gi = graw + pwd * pi;
-    if (OPT == OPT_ADAM) {
-      const P mi = m[i] + (gi - m[i]) * omb1;
-      const P vi = v[i] * pb2 + gi * gi * omb2;
-      pi -= c1 * (mi / (sqrt(vi) / bc2s + peps));
-      m[i] = mi; v[i] = vi;
-    } else if (OPT == OPT_RMSPROP) {
-      const P si_ = v[i] * pa + gi * gi * oma;
-      pi -= plr * (gi / (sqrt(si_) + peps));
-      v[i] = si_;
+      for (int s = sl; s < sj.S; s += lanes) s4 += *reinterpret_cast<const P4*>(in + (long)s * per + q0);
+      acc[0] = s4[0]; acc[1] = s4[1]; acc[2] = s4[2]; acc[3] = s4[3];
     } else {
-      const P mi = m[i] * pb1 + gi * omb1;
-      const P vi = v[i] * pb2 + gi * gi * omb2;
-      const P denom = sqrt(vi) / bc2s + peps;
-      pi -= c1 * (gi / denom);
-      pi -= c2 * (mi / denom);
-      m[i] = mi; v[i] = vi;
+#pragma unroll 8
+      for (int s = sl; s < sj.S; s += lanes) acc[0] += in[(long)s * per + q0];
     }
-    p[i] = pi;
-    if (sh) {
-      const int k = a.pk_k[t];
-      if (k == 0) {
-        sh[i] = (__bf16)(float)pi;
-      } else {   // registered conv weight W[o][ci][j]: keep its packed images current (see emb_conv_pack_register)
-        const int cin = a.pk_cin[t], ii = (int)i, o = ii / (cin * k), rem = ii - o * cin * k, ci = rem / k, j = rem - ci * k;
-        sh[((long)o * k + j) * a.pk_cinpad[t] + ci] = (__bf16)(float)pi;
-        if (a.flip[t]) a.flip[t][((long)ci * k + (k - 1 - j)) * a.pk_cout[t] + o] = (__bf16)(float)pi;
-      }
+  }
+#pragma unroll
+  for (int e = 0; e < 4; ++e) red[e][sl * qpb + qi] = acc[e];
+  __syncthreads();
+  if (sl == 0 && q0 < per) {
+    for (int e = 0; e < sj.vec; ++e) {
+      P sum = 0;
+      for (int i = 0; i < lanes; ++i) sum += red[e][i * qpb + qi];
+      int which;
+      long idx;
+      if (!slab_target(sj, q0 + e, &which, &idx)) continue;
+      const int t = sj.tensor[which];
+      if (t < 0) continue;                   // that output of the job is not a tensor of this launch (it stays queued)
+      a.g[t][idx] = sum;                     // the parameter's .grad holds the summed gradient, as after a reduction launch
+      opt_update<P, OPT>(a, kc, t, idx, sum);
     }
   }
 }
@@ -485,9 +550,7 @@ static int multi_launch(void* const* params, const void* const* grads, void* con
       a.sh[i] = shadows ? (__bf16*)shadows[j] : nullptr;
       a.flip[i] = nullptr;
       a.pk_k[i] = a.pk_cin[i] = a.pk_cinpad[i] = a.pk_cout[i] = 0;
-      a.src[i] = -1;
-      a.which[i] = 0;
-      int per_blk = kChunk;
+      bool plain = true;
       if (i < cnt) {
         if (sizes[j] >= (1ll << 31)) { set_error("optimizer step: tensor of %lld elements", (long long)sizes[j]); return EMB_ERR_ARG; }
         if (sizeof(P) == 4) {
@@ -501,25 +564,27 @@ static int multi_launch(void* const* params, const void* const* grads, void* con
             a.pk_cout[i] = (short)it->second.Cout;
           }
         }
-        // a queued slab reduction that would have produced this gradient: sum its slices here instead (reduce.h)
+        // a queued slab reduction that would have produced this gradient: its slices are summed in this launch (reduce.h)
         ReduceClaim cl;
-        if (nsrc < kMaxSrc + 1 && reduce_claim(grads[j], sizeof(P) == 8, &cl)) {
+        if (reduce_claim(grads[j], sizeof(P) == 8, &cl)) {
           int k = -1;
           for (int q = 0; q < nsrc; ++q)
             if (a.slab[q].in == cl.job.in && a.slab[q].per == cl.job.per) k = q;
           if (k < 0 && nsrc < kMaxSrc) {
             k = nsrc++;
-            a.slab[k].in = cl.job.in; a.slab[k].per = cl.job.per; a.slab[k].S = cl.job.S; a.slab[k].kind = cl.job.kind;
-            for (int q = 0; q < 9; ++q) a.slab[k].iv[q] = cl.job.iv[q];
+            SlabSrc& d = a.slab[k];
+            d.in = cl.job.in; d.per = cl.job.per; d.S = cl.job.S; d.kind = cl.job.kind;
+            for (int q = 0; q < 9; ++q) d.iv[q] = cl.job.iv[q];
+            for (int q = 0; q < 8; ++q) d.tensor[q] = -1;
             int lanes = 1;
-            while (lanes < 16 && lanes * 4 < cl.job.S) lanes *= 2;
-            a.slab[k].lanes = lanes;
+            while (lanes < 16 && lanes < cl.job.S) lanes *= 2;
+            d.lanes = lanes;
+            d.vec = (cl.job.per % 4 == 0 && aligned16(cl.job.in)) ? 4 : 1;
           }
           if (k >= 0) {
-            a.src[i] = (signed char)k;
-            a.which[i] = (signed char)cl.which;
-            per_blk = kChunk / a.slab[k].lanes;
-          } else {                       // table full: put the claim back by running that one reduction the classic way
+            a.slab[k].tensor[cl.which] = (signed char)i;
+            plain = false;
+          } else {                       // table full: run that one reduction the classic way, the gradient is then plain
             ReduceJob one = cl.job;
             for (int q = 0; q < 8; ++q) if (q != cl.which) one.out[q] = nullptr;
             const int rc = sizeof(P) == 8 ? launch_jobs_f64(&one, 1, s) : launch_jobs_f32(&one, 1, s);
@@ -528,10 +593,16 @@ static int multi_launch(void* const* params, const void* const* grads, void* con
         }
       }
       a.n[i] = i < cnt ? (int)sizes[j] : 0;
-      if (i < cnt) blocks += (sizes[j] + per_blk - 1) / per_blk;
+      if (i < cnt && plain) blocks += (sizes[j] + kChunk - 1) / kChunk;
       a.blk_end[i] = (int)blocks;
     }
     a.count = cnt;
+    a.nsrc = nsrc;
+    for (int k = 0; k < nsrc; ++k) {
+      const long epb = (long)(256 / a.slab[k].lanes) * a.slab[k].vec;
+      blocks += (a.slab[k].per + epb - 1) / epb;
+      a.slab[k].blk_end = (int)blocks;
+    }
     a.nstats = 0;
     ReduceJob sj;
     while (a.nstats < 2 && off + cnt >= ntensors && reduce_claim_stats(sizeof(P) == 8, &sj)) {   // (last chunk of the call only)

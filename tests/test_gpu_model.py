@@ -373,10 +373,15 @@ def test_optimizer_launch_sums_the_gradient_slabs_itself(ea, precision, opt_name
     lb, cb, sb, gb = run(True)
     tol = 1e-11 if precision == "float64" else 3e-5
     assert np.array_equal(ca, cb) and np.abs(la - lb).max() < 1e-5
+    # a conv bias in front of BatchNorm has a mathematically zero gradient: what arrives is rounding noise, which the
+    # normalising optimizers turn into +-lr steps -- not comparable between two summation orders
+    noise = lambda k: k.startswith("CNN.CNN_model.") and k.endswith(".bias") and int(k.split(".")[2]) % 5 == 0
     for k in sa:
-        assert (sa[k] - sb[k]).abs().max().item() <= tol * max(1.0, sa[k].abs().max().item()), k
+        if not noise(k):
+            assert (sa[k] - sb[k]).abs().max().item() <= tol * max(1.0, sa[k].abs().max().item()), k
     for k in ga:
-        assert (ga[k] - gb[k]).abs().max().item() <= tol * max(1e-3, ga[k].abs().max().item()), ("grad", k)
+        if not noise(k):
+            assert (ga[k] - gb[k]).abs().max().item() <= tol * max(1e-3, ga[k].abs().max().item()), ("grad", k)
 
 
 def test_captured_steps_survive_workspace_growth_and_cache_release(ea):

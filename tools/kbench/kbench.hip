@@ -59,14 +59,15 @@ static void report_stamps(unsigned long long* dprof, int nblk, const char* const
       ++cnt;
       const double st = (double)(r[1] - w0) * 0.01;          // us (100 MHz wall clock)
       start_sum += st; start_max = std::max(start_max, st);
-      sum[3] += (double)(r[3] - r[2]); sum[4] += (double)(r[4] - r[3]); sum[5] += (double)(r[5] - r[4]); sum[8] += (double)(r[8] - r[5]);
+      sum[3] += (double)(r[3] - r[2]); sum[4] += (double)(r[4] - r[3]); sum[5] += (double)(r[5] - r[4]);
+      if (r[6]) { sum[6] += (double)(r[6] - r[5]); sum[8] += (double)(r[8] - r[6]); } else sum[8] += (double)(r[8] - r[5]);
       // total duration in shader clocks -> us is unknown (clock varies); report cycles
       end_max = std::max(end_max, st);
     }
     if (!cnt) continue;
-    printf("  %-8s n=%4d start avg %.2f max %.2f us | cycles: setup+request %.0f, wait+barrier %.0f, compute (+later rounds) %.0f, store %.0f | total %.0f\n",
-           kind_names[k], cnt, start_sum / cnt, start_max, sum[3] / cnt, sum[4] / cnt, sum[5] / cnt, sum[8] / cnt,
-           (sum[3] + sum[4] + sum[5] + sum[8]) / cnt);
+    printf("  %-8s n=%4d start avg %.2f max %.2f us | cycles: setup+request %.0f, first wait %.0f, main loop %.0f, park %.0f, tail (store / epilogue) %.0f | total %.0f\n",
+           kind_names[k], cnt, start_sum / cnt, start_max, sum[3] / cnt, sum[4] / cnt, sum[5] / cnt, sum[6] / cnt, sum[8] / cnt,
+           (sum[3] + sum[4] + sum[5] + sum[6] + sum[8]) / cnt);
   }
 }
 
@@ -107,14 +108,15 @@ int main(int argc, char** argv) {
   CK(hipMemcpyToSymbol(HIP_SYMBOL(emb::g_split_prof), &null_prof, sizeof(null_prof)));
   const float us = time_graph(s, 100, launch);
   printf("%s B=%d d0=%d d1=%d c=%d S=%d: %.2f us/launch (stamps off)\n", argv[1], B, d0, d1, c, S, us);
-  if (bwd) {
+  {
     CK(hipMemset(dprof, 0, (size_t)max_blk * 16 * 8));
     CK(hipMemcpyToSymbol(HIP_SYMBOL(emb::g_split_prof), &dprof, sizeof(dprof)));
     launch(); CK(hipStreamSynchronize(s));
     CK(hipMemset(dprof, 0, (size_t)max_blk * 16 * 8));
     launch(); CK(hipStreamSynchronize(s));
     static const char* const names[] = {"wgrad0", "wgrad1", "dgrad0", "dgrad1"};
-    report_stamps(dprof, max_blk, names, 4);
+    static const char* const fnames[] = {"fwd"};
+    report_stamps(dprof, max_blk, bwd ? names : fnames, bwd ? 4 : 1);
   }
   return 0;
 }

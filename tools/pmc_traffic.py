@@ -15,7 +15,7 @@ import csv, glob, json, os, sys
 from collections import defaultdict
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-GROUPS = {"embrace_fwd_kernel": ("embrace_fwd",), "embrace_bwd_kernel": ("embrace_bwd_kernel",)}
+GROUPS = {"embrace_fwd_kernel": ("embrace_fwd",), "embrace_bwd_kernel": ("embrace_bwd",)}
 
 
 def mean_counter(directory, counter):
