@@ -44,6 +44,6 @@ int launch_conv_direct(int dtype, bool fwd, const void* x, const void* w, const 
 // slab[S][Cout][KK+1] partial weight gradients (+ bias gradient in column KK); returns S through *S_out
 int launch_conv_wgrad_direct(int dtype, const void* dy, const void* x, void* slab, int B, int L, int cin, int KK, int Cout, int pad,
                              int S, hipStream_t s);
-int conv_wgrad_slices(int B, int L, int pad, int KK, int Cout, int dtype);
+int conv_wgrad_slices(int B, int L, int cin, int pad, int KK, int Cout, int dtype);
 
 }  // namespace emb

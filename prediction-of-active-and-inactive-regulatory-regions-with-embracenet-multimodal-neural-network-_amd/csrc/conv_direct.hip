@@ -1,5 +1,7 @@
 // Direct 1-D convolution kernels (see conv_direct.h).  Reference op: nn.Conv1d of CNN_pre.py:37-38.
 #include "conv_tiles.h"
+#include "conv_wgrad_stream.h"
+#include <cstdlib>
 
 namespace emb {
 
@@ -679,7 +681,14 @@ template <typename T> static int wgrad_slices_t(int B, int L, int pad, int KK, i
   return S;
 }
 
-int conv_wgrad_slices(int B, int L, int pad, int KK, int Cout, int dtype) {
+static bool wgrad_stream_enabled() {
+  static const bool on = [] { const char* e = getenv("EMB_WGRAD_IMPL"); return !(e && e[0] == 'd'); }();   // "direct": the tiled kernel
+  return on;
+}
+
+int conv_wgrad_slices(int B, int L, int cin, int pad, int KK, int Cout, int dtype) {
+  if (dtype == EMB_BF16 && wgrad_stream_enabled() && conv_wgrad_stream_shape_ok(B, L, cin, KK, Cout, pad))
+    return conv_wgrad_stream_slices(B, L, KK, pad);
   switch (dtype) {
     case EMB_F32: return wgrad_slices_t<float>(B, L, pad, KK, Cout);
     case EMB_BF16: return wgrad_slices_t<__bf16>(B, L, pad, KK, Cout);
@@ -713,6 +722,9 @@ template <typename T> static int launch_wgrad_t(const void* dy, const void* x, v
 
 int launch_conv_wgrad_direct(int dtype, const void* dy, const void* x, void* slab, int B, int L, int cin, int KK, int Cout, int pad,
                              int S, hipStream_t s) {
+  if (dtype == EMB_BF16 && wgrad_stream_enabled() && conv_wgrad_stream_shape_ok(B, L, cin, KK, Cout, pad) && aligned16(dy) && aligned16(x) &&
+      S <= conv_tiling(B, L, pad).tiles_m)
+    return launch_wgrad_stream(dy, x, slab, B, L, KK, Cout, pad, S, s);
   switch (dtype) {
     case EMB_F32: return launch_wgrad_t<float>(dy, x, slab, B, L, cin, KK, Cout, pad, S, s);
     case EMB_BF16: return launch_wgrad_t<__bf16>(dy, x, slab, B, L, cin, KK, Cout, pad, S, s);

@@ -568,7 +568,7 @@ template <typename T> static ConvWs conv_workspace(int B, int L, int cin_pad, in
   auto al = [](size_t b) { return (b + 255) & ~(size_t)255; };
   const int pad = (k - 1) / 2;
   const int tiles_direct = conv_tiling(B, L, pad).tiles_m;          // direct kernels tile per sequence
-  const int S_direct = conv_wgrad_slices(B, L, pad, KK, Cout, dtype_code<T>());
+  const int S_direct = conv_wgrad_slices(B, L, cin_pad, pad, KK, Cout, dtype_code<T>());
   const int tiles_stat = w.tiles_m > tiles_direct ? w.tiles_m : tiles_direct;
   w.stat_partial = al((size_t)tiles_stat * 2 * Cout * sizeof(P));
   if (S_direct > S) S = S_direct;
@@ -727,7 +727,7 @@ static int convblock_bwd(const void* dout, int dout_ncl, const uint8_t* argmax, 
   }
   // wgrad: reduction over all B*L rows, split into slices whose partial slabs are reduced in order
   {
-    int S = conv_wgrad_slices(B, L, pad, KK, Cout, dtype_code<T>());
+    int S = conv_wgrad_slices(B, L, cin_pad, pad, KK, Cout, dtype_code<T>());
     int rc = launch_conv_wgrad_direct(dtype_code<T>(), dy, x, slab, B, L, cin_pad, KK, Cout, pad, S, s);
     if (rc == 1) {
       const int tiles_n = cdiv(KK + 1, CW::BN), tiles = cdiv(Cout, CW::BM) * tiles_n;

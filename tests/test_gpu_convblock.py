@@ -49,6 +49,8 @@ CASES = [
     # shorter windows: several whole sequences per 256-row tile of the fused first block, last tile partly filled
     ("short100", 9, [(4, 64, 15), (64, 32, 5)], 100),
     ("short37", 21, [(4, 16, 5)], 37),
+    ("cfg5", 20, [(4, 64, 11), (64, 64, 11)]),            # 64 -> 64 channels: the streaming weight-gradient kernel with 128-byte dy rows
+    ("short70", 33, [(4, 64, 15), (64, 64, 15), (64, 32, 3)], 70),   # L = 31 and 11: four / eleven sequences per 128-row tile
 ]
 
 
