@@ -393,6 +393,10 @@ template <typename T, int BN> static size_t conv_direct_lds(int cin, int SB, int
 constexpr size_t kMaxDirectLds = 150 * 1024;
 
 
+}  // namespace emb
+#include "conv_t_stream.h"
+namespace emb {
+
 // transposed streaming kernel; returns 1 when the shapes do not qualify
 template <typename T, int MT, int WAVES, bool FWD, bool WREG>
 static int launch_conv_t_cfg(const void* x, const void* w, const void* bias, void* out, void* partial, int* partial_rows, int B, int L,
@@ -429,6 +433,17 @@ static int launch_conv_t(const void* x, const void* w, const void* bias, void* o
   constexpr int KSTEP = Mma<T>::KSTEP, VEC = Elem<T>::VEC;
   if (!aligned16(x) || !aligned16(w) || !aligned16(out) || KK % VEC || cin % VEC || (sizeof(T) == 2 && KK % 8)) return 1;
   const bool wreg = cdiv(KK, KSTEP) <= kWRegSteps && MT * kWRegSteps * (int)(sizeof(typename Mma<T>::Frag) / 4) <= 64;
+  if constexpr (sizeof(T) == 2) {   // bf16: operands streamed by LDS-DMA (conv_t_stream.h)
+    static const bool stream_on = [] { const char* e = getenv("EMB_CONVT_IMPL"); return !(e && e[0] == 't'); }();   // "tiled": this file's kernel
+    if (!wreg && stream_on) {
+      const int rows = launch_conv_t_stream<MT, FWD>(x, w, bias, out, partial, B, L, cin, KK, N, pad, s);
+      if (rows < 0) return rows;
+      if (rows > 0) {
+        if (partial_rows) *partial_rows = rows;
+        return EMB_OK;
+      }
+    }
+  }
   if (wreg) return launch_conv_t_cfg<T, MT, 4, FWD, true>(x, w, bias, out, partial, partial_rows, B, L, cin, KK, N, pad, s);
   // weights in LDS: eight waves share them (two per SIMD to cover the LDS latency); four when that does not fit
   const int rc = launch_conv_t_cfg<T, MT, 8, FWD, false>(x, w, bias, out, partial, partial_rows, B, L, cin, KK, N, pad, s);
