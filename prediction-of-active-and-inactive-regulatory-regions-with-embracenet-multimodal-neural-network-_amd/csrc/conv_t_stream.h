@@ -37,7 +37,7 @@ __global__ __launch_bounds__(kCtsWaves * 64, 2) void conv_t_stream_kernel(const 
   constexpr int NT = kCtsNT, WAVES = kCtsWaves, BN = 16 * MT, CPL = 4 * MT;
   constexpr int RS = 4 * CPT, PS = RS + 1, PITCH = PS * 16;              // 16-byte slots per activation row: real, with pad; bytes
   extern __shared__ __attribute__((aligned(16))) char arena[];
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, g = lane >> 4, r16 = lane & 15;
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), g = lane >> 4, r16 = lane & 15;
   const int tn = blockIdx.x / a.nblk_m, bm = blockIdx.x % a.nblk_m, col0 = tn * BN;
   const int tm_begin = bm * a.tpb, tm_end = min(a.tiles_m, tm_begin + a.tpb);
   const int L = a.L, SB = a.SB, slot = a.slot, N = a.N, KK = a.KK;

@@ -65,7 +65,7 @@ __global__ __launch_bounds__(kWsThreads, 2) void conv_wgrad_stream_kernel(const 
   constexpr int BUF = kWsXBytes + DYB;
   extern __shared__ __attribute__((aligned(16))) char arena[];
   const uint32_t lds0 = (uint32_t)(uintptr_t)arena;
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, kg = wave >> 2, wn = wave & 3;
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), kg = wave >> 2, wn = wave & 3;
   const int g = lane >> 4, r16 = lane & 15, q = r16 >> 2, p = r16 & 3;
   // workgroups are dealt round-robin to the 8 XCDs: the n_tiles workgroups of one slice read the same tiles, so they sit on ONE
   // XCD (its L2 fetches the tile once) when the slices divide evenly

@@ -331,6 +331,15 @@ __global__ __launch_bounds__(kMlpThreads) void mlp_bwd_kernel(const MlpBwdArgs<T
   MLP_T(14);
 }
 
+}  // namespace emb
+#include "mlp_mfma.h"
+namespace emb {
+
+static bool mlp_mfma_enabled() {
+  static const bool on = [] { const char* e = getenv("EMB_MLP_IMPL"); return !(e && e[0] == 's'); }();   // "scalar": the LDS dot-product kernels
+  return on;
+}
+
 static int mlp_pitch(int F, const int* N, int L) {
   int m = F;
   for (int l = 0; l < L; ++l) m = N[l] > m ? N[l] : m;
@@ -379,6 +388,24 @@ static int mlp_fwd_t(const void* x, const void* const* W, const void* const* b, 
     a.N[l] = N[l]; a.relu[l] = relu[l]; a.drop[l] = drop[l]; a.layer_id[l] = layer_id[l];
   }
   a.B = B; a.F = F; a.L = L; a.seed = seed; a.step_val = step_val; a.step_dev = step_dev; a.row0 = row0;
+  if constexpr (sizeof(T) == 2) {   // bf16, MFMA-shaped widths: one wave per 16 rows on the matrix cores (mlp_mfma.h)
+    bool al = aligned16(x);
+    for (int l = 0; l < L; ++l) al = al && aligned16(W[l]) && aligned16(h[l]) && (mask[l] == nullptr || aligned16(mask[l]));
+    MmFwdLayout lay{};
+    if (mlp_mfma_enabled() && al && mlp_mfma_ok(F, N, L)) {
+      const size_t lds = mlp_mfma_fwd_layout(F, N, L, &lay);
+      if (lds <= 150 * 1024) {
+        static bool attr2 = false;
+        if (!attr2) {
+          (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&mlp_fwd_mfma_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+          attr2 = true;
+        }
+        mlp_fwd_mfma_kernel<<<cdiv(B, 16), 64, lds, s>>>(a, lay);
+        EMB_CHECK_LAUNCH();
+        return EMB_OK;
+      }
+    }
+  }
   const int pitch = mlp_pitch(F, N, L);
   const size_t lds = (mlp_fwd_lds(F, N, L, sizeof(P)) + 15) & ~(size_t)15;
   static bool attr = false;
@@ -411,6 +438,25 @@ static int mlp_bwd_t(const void* x, const void* const* W, const void* const* h, 
   EMB_CHECK_ARG((int64_t)nblk * total * (int64_t)sizeof(P) <= ws_bytes, "emb_mlp_bwd: workspace too small");
   a.B = B; a.F = F; a.L = L; a.total = total; a.part = (P*)ws;
   ra.L = L; ra.total = total; ra.nblk = nblk;
+  bool launched = false;
+  if constexpr (sizeof(T) == 2) {   // (kMlpRB == 16: the partial-sum layout is the scalar kernel's)
+    bool al = aligned16(x) && aligned16(dy) && (dx == nullptr || aligned16(dx));
+    for (int l = 0; l < L; ++l) al = al && aligned16(W[l]) && aligned16(h[l]) && (mask[l] == nullptr || aligned16(mask[l]));
+    MmBwdLayout lay{};
+    if (mlp_mfma_enabled() && al && mlp_mfma_ok(F, N, L)) {
+      const size_t lds = mlp_mfma_bwd_layout(F, N, L, &lay);
+      if (lds <= 150 * 1024) {
+        static bool attr2 = false;
+        if (!attr2) {
+          (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&mlp_bwd_mfma_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+          attr2 = true;
+        }
+        mlp_bwd_mfma_kernel<<<nblk, 64, lds, s>>>(a, lay);
+        EMB_CHECK_LAUNCH();
+        launched = true;
+      }
+    }
+  }
   const int pitch = mlp_pitch(F, N, L);
   const size_t lds = (mlp_bwd_lds(F, N, L, sizeof(P)) + 15) & ~(size_t)15;
   static bool attr = false;
@@ -418,8 +464,10 @@ static int mlp_bwd_t(const void* x, const void* const* W, const void* const* h, 
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&mlp_bwd_kernel<T>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     attr = true;
   }
-  mlp_bwd_kernel<T><<<nblk, kMlpThreads, lds, s>>>(a, pitch);
-  EMB_CHECK_LAUNCH();
+  if (!launched) {
+    mlp_bwd_kernel<T><<<nblk, kMlpThreads, lds, s>>>(a, pitch);
+    EMB_CHECK_LAUNCH();
+  }
   ReduceJob j{};   // per-workgroup partials -> dW_l / db_l, workgroups summed in fixed order (reduce.hip)
   j.in = ws; j.per = total; j.S = nblk; j.kind = RJ_MLP; j.iv[0] = L;
   for (int l = 0; l < L; ++l) { j.out[l] = ra.dW[l]; j.out[4 + l] = ra.db[l]; j.iv[1 + l] = ra.N[l]; j.iv[5 + l] = ra.K[l]; }

@@ -398,7 +398,10 @@ def test_nadam_bf16_shadow_follows_master(ea):
 @pytest.mark.parametrize("dt", ["f64", "f32", "bf16"])
 @pytest.mark.parametrize("spec", [(100, 48, [(32, True), (16, True), (16, True)]), (37, 562, [(16, True)]),
                                   (64, 256, [(2, False)]), (1024, 58, [(64, True), (32, True), (4, True), (4, True)]),
-                                  (50, 768, [(16, True), (16, True), (2, False)])])
+                                  (50, 768, [(16, True), (16, True), (2, False)]),
+                                  # bf16: the matrix-core kernels (widths % 16 == 0, F % 8 == 0); partial last row block / column tile
+                                  (1000, 152, [(64, True), (32, True)]), (70, 128, [(128, True), (16, False)]),
+                                  (33, 8, [(16, True), (48, True), (16, True), (32, False)])])
 def test_fused_mlp_stack_vs_oracle(ea, spec, dt):
     B, Fin, widths = spec
     T = TD[dt]
@@ -454,3 +457,16 @@ def test_fused_mlp_dropout_matches_per_layer_kernels(ea):
     ref = F.linear(h, w1, b1, relu=True, dropout_p=0.4, layer_id=9, rng=rng)
     assert (fused - ref).abs().max().item() < 1e-5
     assert ((fused == 0) == (ref == 0)).all()
+    # bf16: the matrix-core stack drops the same elements as the per-layer kernels, forward and backward
+    T = torch.bfloat16
+    xs = [x.clone().requires_grad_() for _ in range(2)]
+    ps = [[t.clone().requires_grad_() for t in (w0, b0, w1, b1)] for _ in range(2)]
+    fb = F.mlp(xs[0], [(ps[0][0], ps[0][1], True, 0.3, 8), (ps[0][2], ps[0][3], True, 0.4, 9)], rng=rng, compute_dtype=T)
+    hb = F.linear(xs[1], ps[1][0], ps[1][1], relu=True, dropout_p=0.3, layer_id=8, rng=rng, compute_dtype=T)
+    rb = F.linear(hb, ps[1][2], ps[1][3], relu=True, dropout_p=0.4, layer_id=9, rng=rng, compute_dtype=T)
+    assert ((fb == 0) == (rb == 0)).all() and (fb.float() - rb.float()).abs().max().item() < 2e-2
+    gout = dev(dg.uniform("mlpd/g", (B, 16), -1, 1), T)
+    fb.backward(gout); rb.backward(gout)
+    assert (xs[0].grad.float() - xs[1].grad.float()).abs().max().item() < 3e-2
+    for a_, b_ in zip(ps[0], ps[1]):
+        assert (a_.grad - b_.grad).abs().max().item() < 3e-2 * max(1.0, b_.grad.abs().max().item())

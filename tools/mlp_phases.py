@@ -31,5 +31,6 @@ def run(name, B, Fin, Ns, drops, relus):
 
 
 run("ffnn", 1024, 48, [64, 32, 16], [0.2, 0.3, 0.0], [True] * 3)
+run("cfg2", 1024, 48, [32, 16, 16], [0.0, 0.0, 0.0], [True] * 3)
 run("head", 1024, 256, [2], [0.0], [False])
 run("post2", 1024, 256, [64, 2], [0.4, 0.0], [True, False])
