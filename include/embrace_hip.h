@@ -147,6 +147,18 @@ int emb_nadam_step(void* param, const void* grad, void* exp_avg, void* exp_avg_s
                    double weight_decay, double schedule_decay, uint64_t step_val, const uint64_t* step_dev,
                    int dtype, emb_stream_t stream);
 
+/* Riders (csrc/rider.h).  The epigenomic MLP stack (FFNN_pre.py) and the sequence CNN (CNN_pre.py) are independent until the
+ * EmbraceNet layer joins them; the MLP launches are tiny and latency-bound.  With deferral armed on the calling thread
+ * (emb_rider_defer(1)), an emb_mlp_fwd / emb_mlp_bwd call that takes the bf16 matrix-core kernels (widths % 16 == 0, F % 8 == 0)
+ * does NOT launch: it is parked and carried as the first workgroups of the next carrier launch on the same stream --
+ * emb_convblock_fwd's statistics pass of the fused first block for a forward, emb_convblock_bwd's BatchNorm gather pass of a
+ * stored-activation block for a backward -- so the two chains overlap on the CUs without a second stream.  emb_rider_defer(0)
+ * disarms (a parked launch stays parked); emb_rider_flush() launches a parked rider on its own.  The optimizer and reduction
+ * entry points flush first.  The caller keeps every tensor of a parked launch alive, and does not read its outputs, until a
+ * carrier has run or the flush.  At most one rider is parked per thread (parking a second one flushes the first). */
+int emb_rider_defer(int on);
+int emb_rider_flush(void);
+
 /* Small MLP stacks fused into one forward launch and two backward launches (FFNN_pre.py:18-49; the post stack
  * and the Linear(->2) head of EmbraceNetMultimodal.py:134-154).  L <= 4 layers, Y_l = dropout(relu(Y_{l-1} W_l^T +
  * b_l)) with per-layer relu flag / dropout_p / RNG layer id.  Pointer and int arrays are HOST arrays of length L
@@ -154,7 +166,7 @@ int emb_nadam_step(void* param, const void* grad, void* exp_avg, void* exp_avg_s
  * mask[l] [B][N_l] u8 its mask byte (entry may be NULL for a layer with neither ReLU nor dropout).
  * emb_mlp_supported() tells whether a stack fits the kernel's LDS budget; otherwise call emb_linear_* per layer.
  * emb_mlp_bwd: dy [B][N_{L-1}] T -> dx [B][F] T (nullable), dW[l] [N_l][K_l] P, db[l] [N_l] P; workspace holds
- * ceil(B/32) (ceil(B/16) for EMB_F64) partial sums of all weight gradients, reduced in fixed order. */
+ * ceil(B/16) partial sums of all weight gradients, reduced in fixed order. */
 int emb_mlp_supported(int F, const int* N, int L, int dtype);
 /* bytes of `workspace` emb_mlp_bwd needs for a batch of B rows (0 when the stack is not eligible) */
 int64_t emb_mlp_workspace_bytes(int F, const int* N, int L, int B, int dtype);

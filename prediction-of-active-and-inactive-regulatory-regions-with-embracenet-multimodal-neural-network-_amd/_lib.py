@@ -42,6 +42,8 @@ SIGNATURES = {
     "emb_mlp_supported": [_i, _vp, _i, _i],
     "emb_mlp_workspace_bytes": [_i, _vp, _i, _i, _i],
     "emb_mlp_fwd": [_vp] * 9 + [_i, _i, _i, _u64, _u64, _vp, _i64, _i, _vp],
+    "emb_rider_defer": [_i],
+    "emb_rider_flush": [],
     "emb_mlp_bwd": [_vp] * 11 + [_i, _i, _i, _vp, _i64, _i, _vp],
     "emb_adam_step_multi": [_vp] * 6 + [_i, _d, _d, _d, _d, _d, _u64, _vp, _i, _vp],
     "emb_rmsprop_step_multi": [_vp] * 5 + [_i, _d, _d, _d, _d, _i, _vp],

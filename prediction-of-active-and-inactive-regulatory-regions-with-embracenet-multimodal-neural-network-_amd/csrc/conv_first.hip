@@ -21,6 +21,7 @@
 // stored-activation kernels).
 #include "conv_first.h"
 #include "conv_tiles.h"
+#include "rider.h"
 #include "philox.h"
 
 namespace emb {
@@ -67,7 +68,7 @@ __host__ __device__ constexpr int first_plo(int t) { return t >= 9 ? (t - 8) / 2
 // quarter, channel group).  Splitting the channels over wave pairs halves the per-wave register state (weights, constants,
 // accumulators) so that 8 waves fit on a CU.
 template <int MT, int CH, int MODE>
-__global__ __launch_bounds__(256 * CH) void first_kernel(const FirstArgs a) {
+__device__ __forceinline__ void first_body(const FirstArgs& a, const int bm) {
   using Mm = Mma<__bf16>;
   using T = __bf16;
   typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
@@ -88,7 +89,7 @@ __global__ __launch_bounds__(256 * CH) void first_kernel(const FirstArgs a) {
   float* red = reinterpret_cast<float*>(rowmap + (MODE == F_BWGRAD ? kFBT : 0));                      // [4][2][BN]
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, g = lane >> 4, r16 = lane & 15;
   const int grp = wave % CH, rq = wave / CH, gcol = grp * GW;   // channel group, row quarter, first channel of the group
-  const int bm = blockIdx.x, tm_begin = bm * a.tpb, tm_end = min(a.tiles_m, tm_begin + a.tpb);
+  const int tm_begin = bm * a.tpb, tm_end = min(a.tiles_m, tm_begin + a.tpb);
 
   FIRST_T(0);
   // ---- this thread's share of the activation tile (tile independent)
@@ -628,6 +629,23 @@ __global__ __launch_bounds__(256 * CH) void first_kernel(const FirstArgs a) {
   FIRST_T(41);
 }
 
+template <int MT, int CH, int MODE>
+__global__ __launch_bounds__(256 * CH) void first_kernel(const FirstArgs a) {
+  first_body<MT, CH, MODE>(a, (int)blockIdx.x);
+}
+
+// the statistics pass carrying the forward of the epigenomic MLP stack as its first `nr` workgroups (rider.h): one wave of each
+// runs 16 rows of the stack, the pass's own workgroups follow
+template <int MT, int CH>
+__global__ __launch_bounds__(256 * CH) void first_stats_rider_kernel(const FirstArgs a, const MlpArgs<__bf16> fa, const MmFwdLayout fl, const int nr) {
+  if ((int)blockIdx.x < nr) {
+    extern __shared__ __attribute__((aligned(16))) char rider_arena[];
+    if (threadIdx.x < 64) mlp_fwd_mfma_body(fa, fl, (int)blockIdx.x, rider_arena);
+    return;
+  }
+  first_body<MT, CH, F_STATS>(a, (int)blockIdx.x - nr);
+}
+
 #ifdef EMB_CONV_PROF
 extern "C" int emb_debug_first_prof(unsigned long long* out, int select) {
   int rc = (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_first_prof), sizeof(unsigned long long) * 64);
@@ -684,6 +702,27 @@ int conv_first_blocks(int B, int L, int cin_pad, int Cout, int k) {
 
 template <int MODE> static int first_launch(FirstArgs& a, const FirstGeom& gm, hipStream_t s) {
   const size_t lds = first_lds(MODE, gm, a.Lp, a.C);
+  if (MODE == F_STATS) {   // a parked MLP forward of this stream rides along (rider.h)
+    Rider r;
+    if (rider_take(s, RIDER_MLP_FWD, &r)) {
+      const size_t lds2 = lds > r.lds ? lds : r.lds;
+      auto go2 = [&](auto kern, int threads) {
+        static bool attr = false;
+        if (!attr) {
+          (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
+          attr = true;
+        }
+        kern<<<gm.nblk + r.nwg, threads, lds2, s>>>(a, r.fa, r.fl, r.nwg);
+      };
+      switch (a.C) {
+        case 16: go2(&first_stats_rider_kernel<1, 1>, 256); break;
+        case 32: go2(&first_stats_rider_kernel<2, 1>, 256); break;
+        default: go2(&first_stats_rider_kernel<2, 2>, 512); break;
+      }
+      EMB_CHECK_LAUNCH();
+      return EMB_OK;
+    }
+  }
   auto go = [&](auto kern, int threads) {
     static bool attr = false;
     if (!attr) {

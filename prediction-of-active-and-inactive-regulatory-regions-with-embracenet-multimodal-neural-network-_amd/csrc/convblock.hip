@@ -14,6 +14,7 @@
 // pooled gradient by a deterministic gather (no atomics anywhere: results are bitwise reproducible).
 #include "conv_direct.h"
 #include "conv_first.h"
+#include "rider.h"
 #include "reduce.h"
 #include "gemm_tile.h"
 
@@ -295,15 +296,15 @@ template <typename T> static int bn_bwd_tile(int C) {
 }
 
 template <typename T, bool NCL_IN>
-__global__ __launch_bounds__(256) void bn_bwd_dz_kernel(const T* __restrict__ dout, const uint8_t* __restrict__ argmax,
-                                                        const T* __restrict__ y, const typename AccOf<T>::type* __restrict__ stats,
-                                                        T* __restrict__ dz_out, typename AccOf<T>::type* __restrict__ bpart, int L,
-                                                        int Lp, int C, float keep_scale, int TT, int tiles_per_seq) {
+__device__ __forceinline__ void bn_bwd_dz_body(const T* __restrict__ dout, const uint8_t* __restrict__ argmax,
+                                               const T* __restrict__ y, const typename AccOf<T>::type* __restrict__ stats,
+                                               T* __restrict__ dz_out, typename AccOf<T>::type* __restrict__ bpart, int L,
+                                               int Lp, int C, float keep_scale, int TT, int tiles_per_seq, const int bid) {
   using Acc = typename AccOf<T>::type;
   constexpr int VEC = Elem<T>::VEC;
   using V = typename Vec16<T>::type;
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  const int b = blockIdx.x / tiles_per_seq, t0 = (blockIdx.x % tiles_per_seq) * TT;
+  const int b = bid / tiles_per_seq, t0 = (bid % tiles_per_seq) * TT;
   const int t_end = min(L, t0 + TT);
   const int P0 = pool_plo(t0), P1 = min(Lp - 1, (t_end - 1) / 2), NP = P1 - P0 + 1;   // NP <= TT/2 + 5
   const int NPmax = TT / 2 + 5;
@@ -388,8 +389,31 @@ __global__ __launch_bounds__(256) void bn_bwd_dz_kernel(const T* __restrict__ do
   for (int i = threadIdx.x; i < 2 * C; i += 256) {
     Acc a = 0;
     for (int q = 0; q < TY; ++q) a += red[(long)q * RP + i];
-    bpart[(long)blockIdx.x * 2 * C + i] = a;
+    bpart[(long)bid * 2 * C + i] = a;
   }
+}
+
+template <typename T, bool NCL_IN>
+__global__ __launch_bounds__(256) void bn_bwd_dz_kernel(const T* __restrict__ dout, const uint8_t* __restrict__ argmax,
+                                                        const T* __restrict__ y, const typename AccOf<T>::type* __restrict__ stats,
+                                                        T* __restrict__ dz_out, typename AccOf<T>::type* __restrict__ bpart, int L,
+                                                        int Lp, int C, float keep_scale, int TT, int tiles_per_seq) {
+  bn_bwd_dz_body<T, NCL_IN>(dout, argmax, y, stats, dz_out, bpart, L, Lp, C, keep_scale, TT, tiles_per_seq, (int)blockIdx.x);
+}
+
+// the gather pass carrying the backward of the epigenomic MLP stack as its first `nr` workgroups (rider.h)
+template <bool NCL_IN>
+__global__ __launch_bounds__(256) void bn_bwd_dz_rider_kernel(const __bf16* __restrict__ dout, const uint8_t* __restrict__ argmax,
+                                                              const __bf16* __restrict__ y, const float* __restrict__ stats,
+                                                              __bf16* __restrict__ dz_out, float* __restrict__ bpart, int L, int Lp, int C,
+                                                              float keep_scale, int TT, int tiles_per_seq, const MlpBwdArgs<__bf16> ba,
+                                                              const MmBwdLayout bl, const int nr) {
+  if ((int)blockIdx.x < nr) {
+    extern __shared__ __attribute__((aligned(16))) char rider_arena[];
+    if (threadIdx.x < 64) mlp_bwd_mfma_body(ba, bl, (int)blockIdx.x, rider_arena);
+    return;
+  }
+  bn_bwd_dz_body<__bf16, NCL_IN>(dout, argmax, y, stats, dz_out, bpart, L, Lp, C, keep_scale, TT, tiles_per_seq, (int)blockIdx.x - nr);
 }
 
 // finalise dgamma / dbeta and the two per-channel means the apply pass needs: coef[0][c] = mean(dz), coef[1][c] = mean(dz*xhat)
@@ -707,7 +731,26 @@ static int convblock_bwd(const void* dout, int dout_ncl, const uint8_t* argmax, 
       const size_t sm_red = (size_t)TY * (2 * Cout + 1) * sizeof(P);
       if (sm_red > sm) sm = sm_red;
       sm = (sm + 15) & ~(size_t)15;
-      if (dout_ncl)
+      Rider rd;
+      bool carried = false;
+      if constexpr (sizeof(T) == 2) {   // a parked MLP backward of this stream rides along (rider.h)
+        if (rider_take(s, RIDER_MLP_BWD, &rd)) {
+          const size_t sm2 = sm > rd.lds ? sm : rd.lds;
+          static bool attr = false;
+          if (!attr) {
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&bn_bwd_dz_rider_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&bn_bwd_dz_rider_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
+            attr = true;
+          }
+          if (dout_ncl)
+            bn_bwd_dz_rider_kernel<true><<<w.nblk_bwd + rd.nwg, 256, sm2, s>>>((const T*)dout, argmax, (const T*)y, (const P*)stats, (T*)dy, bpart, L, Lp, Cout, keep_scale, TT, tiles_per_seq, rd.ba, rd.bl, rd.nwg);
+          else
+            bn_bwd_dz_rider_kernel<false><<<w.nblk_bwd + rd.nwg, 256, sm2, s>>>((const T*)dout, argmax, (const T*)y, (const P*)stats, (T*)dy, bpart, L, Lp, Cout, keep_scale, TT, tiles_per_seq, rd.ba, rd.bl, rd.nwg);
+          carried = true;
+        }
+      }
+      if (carried) {
+      } else if (dout_ncl)
         bn_bwd_dz_kernel<T, true><<<w.nblk_bwd, 256, sm, s>>>((const T*)dout, argmax, (const T*)y, (const P*)stats, (T*)dy, bpart, L, Lp, Cout, keep_scale, TT, tiles_per_seq);
       else
         bn_bwd_dz_kernel<T, false><<<w.nblk_bwd, 256, sm, s>>>((const T*)dout, argmax, (const T*)y, (const P*)stats, (T*)dy, bpart, L, Lp, Cout, keep_scale, TT, tiles_per_seq);

@@ -291,6 +291,7 @@ extern "C" int emb_counter_add(uint64_t* counter, uint64_t inc, emb_stream_t str
 #include <mutex>
 #include <unordered_map>
 #include "reduce.h"
+#include "rider.h"
 namespace emb {
 int launch_jobs_f32(const ReduceJob* jobs, int n, hipStream_t s);   // reduce.hip
 int launch_jobs_f64(const ReduceJob* jobs, int n, hipStream_t s);
@@ -535,6 +536,10 @@ static std::mutex& pack_mutex() {
 template <typename P, int OPT>
 static int multi_launch(void* const* params, const void* const* grads, void* const* s1, void* const* s2, void* const* shadows,
                         const int64_t* sizes, int ntensors, const Hyper& h, hipStream_t s) {
+  {   // a parked rider launch (rider.h) may be the producer of a slab this launch is about to consume
+    const int rcr = rider_flush();
+    if (rcr != EMB_OK) return rcr;
+  }
   for (int off = 0; off < ntensors; off += kMaxTensors) {
     const int cnt = ntensors - off < kMaxTensors ? ntensors - off : kMaxTensors;
     MultiArgs<P> a;

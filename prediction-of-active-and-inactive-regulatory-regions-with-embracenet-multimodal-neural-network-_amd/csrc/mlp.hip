@@ -13,40 +13,10 @@
 #include "common.h"
 #include "philox.h"
 #include "reduce.h"
+#include "mlp_args.h"
+#include "rider.h"
 
 namespace emb {
-
-constexpr int kMlpMaxL = 4, kMlpWBudget = 12288;   // LDS elements for all weights of the stack
-constexpr int kMlpRB = 16, kMlpThreads = 1024;     // rows per workgroup, threads per workgroup
-
-template <typename T> struct MlpArgs {
-  using P = typename AccOf<T>::type;
-  const T* x;            // [B][F]
-  const T* W[kMlpMaxL];  // [N_l][K_l] in compute dtype
-  const P* b[kMlpMaxL];
-  T* h[kMlpMaxL];        // outputs of every layer [B][N_l] (the last one is the result)
-  uint8_t* mask[kMlpMaxL];   // bit0 pre-activation > 0, bit1 kept by dropout (nullable when the layer has neither)
-  int N[kMlpMaxL], relu[kMlpMaxL], layer_id[kMlpMaxL];
-  float drop[kMlpMaxL];
-  int B, F, L;
-  uint64_t seed, step_val;
-  const uint64_t* step_dev;
-  int64_t row0;
-};
-
-template <typename T> struct MlpBwdArgs {
-  using P = typename AccOf<T>::type;
-  const T* x;
-  const T* W[kMlpMaxL];
-  const T* h[kMlpMaxL];
-  const uint8_t* mask[kMlpMaxL];
-  const T* dy;           // [B][N_{L-1}]
-  T* dx;                 // [B][F] or nullptr
-  P* part;               // [nblk][total] partial sums; layout per layer: dW [N][K] then db [N]
-  int N[kMlpMaxL], relu[kMlpMaxL];
-  float drop[kMlpMaxL];
-  int B, F, L, total;
-};
 
 struct MlpReduceArgs {
   void* dW[kMlpMaxL];
@@ -395,13 +365,14 @@ static int mlp_fwd_t(const void* x, const void* const* W, const void* const* b, 
     if (mlp_mfma_enabled() && al && mlp_mfma_ok(F, N, L)) {
       const size_t lds = mlp_mfma_fwd_layout(F, N, L, &lay);
       if (lds <= 150 * 1024) {
-        static bool attr2 = false;
-        if (!attr2) {
-          (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&mlp_fwd_mfma_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-          attr2 = true;
+        Rider r{};
+        r.kind = RIDER_MLP_FWD; r.nwg = cdiv(B, 16); r.lds = lds; r.stream = s; r.fa = a; r.fl = lay;
+        if (rider_deferring()) {   // carried by the next suitable launch of this stream (rider.h)
+          rider_park(r);
+          return EMB_OK;
         }
-        mlp_fwd_mfma_kernel<<<cdiv(B, 16), 64, lds, s>>>(a, lay);
-        EMB_CHECK_LAUNCH();
+        const int rc = rider_launch(r);
+        if (rc != EMB_OK) return rc;
         return EMB_OK;
       }
     }
@@ -446,13 +417,14 @@ static int mlp_bwd_t(const void* x, const void* const* W, const void* const* h, 
     if (mlp_mfma_enabled() && al && mlp_mfma_ok(F, N, L)) {
       const size_t lds = mlp_mfma_bwd_layout(F, N, L, &lay);
       if (lds <= 150 * 1024) {
-        static bool attr2 = false;
-        if (!attr2) {
-          (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&mlp_bwd_mfma_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-          attr2 = true;
+        Rider r{};
+        r.kind = RIDER_MLP_BWD; r.nwg = nblk; r.lds = lds; r.stream = s; r.ba = a; r.bl = lay;
+        if (rider_deferring() && reduce_deferring()) {   // (an immediate reduction launch below would overtake a parked producer)
+          rider_park(r);
+        } else {
+          const int rc = rider_launch(r);
+          if (rc != EMB_OK) return rc;
         }
-        mlp_bwd_mfma_kernel<<<nblk, 64, lds, s>>>(a, lay);
-        EMB_CHECK_LAUNCH();
         launched = true;
       }
     }

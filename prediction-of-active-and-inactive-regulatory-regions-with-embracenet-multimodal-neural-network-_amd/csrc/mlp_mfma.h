@@ -15,6 +15,7 @@
 // A workgroup is one wave: no barriers anywhere; 64 workgroups at B = 1024.
 #pragma once
 #include "common.h"
+#include "mlp_args.h"
 #include "philox.h"
 #include "split_core.h"
 
@@ -40,6 +41,10 @@ struct MmBwdLayout {
   int zero_begin, zero_end;                 // byte range cleared at start (covers every pad region)
 };
 
+// NOTE on the layer loops below: they are written with the constant trip count kMlpMaxL, fully unrolled, and skip layers >= L.
+// Indexing a by-value kernel argument array with a run-time layer index would make the compiler keep the whole argument block in
+// scratch memory (select chains are folded back into an indexed load); after full unrolling every subscript is a constant.
+
 __device__ __forceinline__ bf16x8 mm_zero8() {
   bf16x8 z;
 #pragma unroll
@@ -64,17 +69,20 @@ __device__ __forceinline__ void mm_dma_copy(const void* src, long valid, int byt
 #endif
 }
 
-__global__ __launch_bounds__(64) void mlp_fwd_mfma_kernel(const MlpArgs<__bf16> a, const MmFwdLayout lay) {
+// one wave, 16 rows starting at 16 * blk; `smraw` = the wave's LDS (layout `lay`).  No barriers: callable from any kernel whose
+// other waves do something else (rider.h).
+__device__ __forceinline__ void mlp_fwd_mfma_body(const MlpArgs<__bf16>& a, const MmFwdLayout& lay, int blk, char* smraw) {
   using T = __bf16;
-  extern __shared__ __attribute__((aligned(16))) char smraw[];
   const uint32_t lds0 = (uint32_t)(uintptr_t)smraw;
-  const int lane = threadIdx.x, g = lane >> 4, r16 = lane & 15;
-  const int rb = blockIdx.x * 16, L = a.L, AP = lay.AP;
+  const int lane = threadIdx.x & 63, g = lane >> 4, r16 = lane & 15;
+  const int rb = blk * 16, L = a.L, AP = lay.AP;
 
 #if defined(__HIP_DEVICE_COMPILE__)
   {   // every layer's weights as fragment-ready blocks: lane (n = r16, k group g) of block (nt, ks) holds W[16 nt + n][32 ks + 8 g ..]
     int K = a.F;
-    for (int l = 0; l < L; ++l) {
+#pragma unroll
+    for (int l = 0; l < kMlpMaxL; ++l) {
+      if (l >= L) continue;
       const int N = a.N[l], nks = (K + 31) >> 5, NT = N >> 4;
       const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc((void*)a.W[l], 0, N * K * 2, 0x00020000);
       for (int nt = 0; nt < NT; ++nt)
@@ -87,7 +95,9 @@ __global__ __launch_bounds__(64) void mlp_fwd_mfma_kernel(const MlpArgs<__bf16> 
     }
   }
 #endif
-  for (int l = 0; l < L; ++l) {
+#pragma unroll
+  for (int l = 0; l < kMlpMaxL; ++l) {
+    if (l >= L) continue;
     float* bl = reinterpret_cast<float*>(smraw + lay.bias[l]);
     for (int n = lane; n < a.N[l]; n += 64) bl[n] = a.b[l][n];
   }
@@ -104,11 +114,13 @@ __global__ __launch_bounds__(64) void mlp_fwd_mfma_kernel(const MlpArgs<__bf16> 
   EMB_WAIT_VMCNT(0);   // the LDS-DMA blocks have landed (the compiler does not order LDS reads behind LDS-DMA by itself)
 
   int K = a.F;
-  for (int l = 0; l < L; ++l) {
+#pragma unroll
+  for (int l = 0; l < kMlpMaxL; ++l) {
+    if (l >= L) continue;
     const int N = a.N[l], nks = (K + 31) >> 5, NT = N >> 4;
     const uint32_t wb = lds0 + lay.wblk[l] + (uint32_t)lane * 16u;
     const float* bl = reinterpret_cast<const float*>(smraw + lay.bias[l]);
-    T* out = reinterpret_cast<T*>(smraw + lay.act[l & 1]);
+    T* out = reinterpret_cast<T*>(smraw + lay.act[(l) & 1]);
     uint8_t* mk = reinterpret_cast<uint8_t*>(smraw + lay.msk);
     const float p = a.drop[l], keep_scale = p > 0.f ? 1.0f / (1.0f - p) : 1.0f;
     const uint64_t stream = rng_stream(step, EMB_RNG_DROPOUT0 + a.layer_id[l]);
@@ -160,12 +172,12 @@ __global__ __launch_bounds__(64) void mlp_fwd_mfma_kernel(const MlpArgs<__bf16> 
   }
 }
 
-__global__ __launch_bounds__(64) void mlp_bwd_mfma_kernel(const MlpBwdArgs<__bf16> a, const MmBwdLayout lay) {
+
+__device__ __forceinline__ void mlp_bwd_mfma_body(const MlpBwdArgs<__bf16>& a, const MmBwdLayout& lay, int blk, char* smraw) {
   using T = __bf16;
-  extern __shared__ __attribute__((aligned(16))) char smraw[];
   const uint32_t lds0 = (uint32_t)(uintptr_t)smraw;
-  const int lane = threadIdx.x, g = lane >> 4, r16 = lane & 15, q = r16 >> 2, p4 = r16 & 3;
-  const int rb = blockIdx.x * 16, L = a.L, NP = lay.NP;
+  const int lane = threadIdx.x & 63, g = lane >> 4, r16 = lane & 15, q = r16 >> 2, p4 = r16 & 3;
+  const int rb = blk * 16, L = a.L, NP = lay.NP;
   const long rows_left = (long)a.B - rb;                        // > 0
 
   // pad regions (rows 16..31 of the K-major images, weight rows past N) must hold zeros: clear the whole range first
@@ -173,42 +185,47 @@ __global__ __launch_bounds__(64) void mlp_bwd_mfma_kernel(const MlpBwdArgs<__bf1
   __builtin_amdgcn_s_waitcnt(0xc07f);                           // lgkmcnt(0): the clears precede the LDS-DMA writes below
   {
     int K = a.F;
-    for (int l = 0; l < L; ++l) {
+#pragma unroll
+    for (int l = 0; l < kMlpMaxL; ++l) {
+      if (l >= L) continue;
       const int N = a.N[l];
       if (l > 0 || a.dx != nullptr) mm_dma_copy(a.W[l], (long)N * K * 2, N * K * 2, lds0 + lay.wimg[l], lane);
-      const T* hsrc = l == 0 ? a.x : a.h[l - 1];
+      const T* hsrc = l == 0 ? a.x : a.h[l > 0 ? l - 1 : 0];
       mm_dma_copy(hsrc + (long)rb * K, rows_left * K * 2, 16 * K * 2, lds0 + lay.hin[l], lane);
       if (a.mask[l] != nullptr) mm_dma_copy(a.mask[l] + (long)rb * N, rows_left * N, 16 * N, lds0 + lay.msk[l], lane);
       K = N;
     }
-    const int NL = a.N[L - 1];
+    int NL = a.N[0];
+#pragma unroll
+    for (int l = 1; l < kMlpMaxL; ++l) NL = (l == L - 1) ? a.N[l] : NL;
     mm_dma_copy(a.dy + (long)rb * NL, rows_left * NL * 2, 16 * NL * 2, lds0 + lay.dy, lane);
   }
   EMB_WAIT_VMCNT(0);   // the LDS-DMA copies have landed (the compiler does not order LDS reads behind LDS-DMA by itself)
-  // dz of the last layer = dy * mask factor
-  {
-    const int l = L - 1, N = a.N[l];
-    const uint8_t need = (uint8_t)((a.relu[l] ? 1 : 0) | (a.drop[l] > 0.f ? 2 : 0));
-    const float scale = a.drop[l] > 0.f ? 1.0f / (1.0f - a.drop[l]) : 1.0f;
-    const T* dyt = reinterpret_cast<const T*>(smraw + lay.dy);
-    const uint8_t* mk = reinterpret_cast<const uint8_t*>(smraw + lay.msk[l]);
-    T* dz = reinterpret_cast<T*>(smraw + lay.dz[l & 1]);
-    for (int i = lane; i < 16 * N; i += 64) {
-      const int tr = i / N, n = i - tr * N;
-      const uint8_t m = a.mask[l] != nullptr ? mk[i] : (uint8_t)3;
-      const float v = (float)dyt[i];
-      dz[tr * NP + n] = (T)(((m & need) == need && rb + tr < a.B) ? v * scale : 0.0f);
+#pragma unroll
+  for (int li = 0; li < kMlpMaxL; ++li) {
+    const int l = kMlpMaxL - 1 - li;
+    if (l >= L) continue;
+    const int N = a.N[l], K = l == 0 ? a.F : a.N[l > 0 ? l - 1 : 0];
+    if (l == L - 1) {   // dz of the last layer = dy * mask factor
+      const uint8_t need = (uint8_t)((a.relu[l] ? 1 : 0) | (a.drop[l] > 0.f ? 2 : 0));
+      const float scale = a.drop[l] > 0.f ? 1.0f / (1.0f - a.drop[l]) : 1.0f;
+      const T* dyt = reinterpret_cast<const T*>(smraw + lay.dy);
+      const uint8_t* mk = reinterpret_cast<const uint8_t*>(smraw + lay.msk[l]);
+      T* dz = reinterpret_cast<T*>(smraw + lay.dz[l & 1]);
+      for (int i = lane; i < 16 * N; i += 64) {
+        const int tr = i / N, n = i - tr * N;
+        const uint8_t m = a.mask[l] != nullptr ? mk[i] : (uint8_t)3;
+        const float v = (float)dyt[i];
+        dz[tr * NP + n] = (T)(((m & need) == need && rb + tr < a.B) ? v * scale : 0.0f);
+      }
     }
-  }
-
-  int off_end = a.total;
-  for (int l = L - 1; l >= 0; --l) {
-    const int N = a.N[l], K = l == 0 ? a.F : a.N[l - 1];
-    const int off = off_end - N * (K + 1);
-    off_end = off;
-    float* part = a.part + (long)blockIdx.x * a.total + off;
-    const uint32_t dzb = lds0 + lay.dz[l & 1];
-    const T* dz = reinterpret_cast<const T*>(smraw + lay.dz[l & 1]);
+    int off = 0;                                                  // this layer's block in the partial vector: dW [N][K], db [N]
+#pragma unroll
+    for (int j = 0; j < kMlpMaxL; ++j)
+      if (j < l) off += a.N[j] * ((j == 0 ? a.F : a.N[j > 0 ? j - 1 : 0]) + 1);
+    float* part = a.part + (long)blk * a.total + off;
+    const uint32_t dzb = lds0 + lay.dz[(l) & 1];
+    const T* dz = reinterpret_cast<const T*>(smraw + lay.dz[(l) & 1]);
     // db[n] = sum of dz over the 16 rows
     for (int n = lane; n < N; n += 64) {
       float s = 0.0f;
@@ -249,9 +266,9 @@ __global__ __launch_bounds__(64) void mlp_bwd_mfma_kernel(const MlpBwdArgs<__bf1
       const uint8_t* mk = nullptr;
       T* dzn = nullptr;
       if (l > 0) {
-        need = (uint8_t)((a.relu[l - 1] ? 1 : 0) | (a.drop[l - 1] > 0.f ? 2 : 0));
-        scale = a.drop[l - 1] > 0.f ? 1.0f / (1.0f - a.drop[l - 1]) : 1.0f;
-        mk = a.mask[l - 1] != nullptr ? reinterpret_cast<const uint8_t*>(smraw + lay.msk[l - 1]) : nullptr;
+        need = (uint8_t)((a.relu[l > 0 ? l - 1 : 0] ? 1 : 0) | (a.drop[l > 0 ? l - 1 : 0] > 0.f ? 2 : 0));
+        scale = a.drop[l > 0 ? l - 1 : 0] > 0.f ? 1.0f / (1.0f - a.drop[l > 0 ? l - 1 : 0]) : 1.0f;
+        mk = a.mask[l > 0 ? l - 1 : 0] != nullptr ? reinterpret_cast<const uint8_t*>(smraw + lay.msk[l > 0 ? l - 1 : 0]) : nullptr;
         dzn = reinterpret_cast<T*>(smraw + lay.dz[(l - 1) & 1]);
       }
       for (int ct = 0; ct < CT; ++ct) {
@@ -277,6 +294,7 @@ __global__ __launch_bounds__(64) void mlp_bwd_mfma_kernel(const MlpBwdArgs<__bf1
     }
   }
 }
+
 
 // ---- host side
 static bool mlp_mfma_ok(int F, const int* N, int L) {

@@ -20,6 +20,7 @@ struct ReduceJob {
 
 // immediate mode: launches on `s`; deferred mode: queued until emb_reduce_flush().  is_double selects P.
 int reduce_submit(const ReduceJob& job, bool is_double, hipStream_t s);
+bool reduce_deferring();   // submitted jobs are queued (emb_reduce_defer) rather than launched at once
 
 // Queued jobs as seen by the multi-tensor optimizer launch (loss_optim.hip), which sums the slices of a gradient itself
 // instead of reading the reduced tensor: `reduce_claim` looks for a queued job with an output == `grad`, returns its

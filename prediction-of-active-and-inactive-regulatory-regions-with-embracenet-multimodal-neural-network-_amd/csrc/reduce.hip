@@ -2,6 +2,7 @@
 #include <vector>
 
 #include "reduce.h"
+#include "rider.h"
 
 namespace emb {
 
@@ -169,6 +170,8 @@ bool reduce_claim_stats(bool is_double, ReduceJob* out) {
 int launch_jobs_f32(const ReduceJob* jobs, int n, hipStream_t s) { return launch_jobs<float>(jobs, n, s); }
 int launch_jobs_f64(const ReduceJob* jobs, int n, hipStream_t s) { return launch_jobs<double>(jobs, n, s); }
 
+bool reduce_deferring() { return g_defer; }
+
 int reduce_submit(const ReduceJob& job, bool is_double, hipStream_t s) {
   if (job.per <= 0 || job.S <= 0) return EMB_OK;
   if (g_defer) {
@@ -188,7 +191,8 @@ extern "C" int emb_reduce_defer(int on) {
 
 extern "C" int emb_reduce_flush(emb_stream_t stream) {
   emb::Pending& p = emb::pending();
-  int rc = EMB_OK;
+  int rc = emb::rider_flush();   // a parked launch may be the producer of a queued slab
+  if (rc != EMB_OK) return rc;
   if (!p.f32.empty()) rc = emb::launch_jobs<float>(p.f32.data(), (int)p.f32.size(), (hipStream_t)stream);
   if (rc == EMB_OK && !p.f64.empty()) rc = emb::launch_jobs<double>(p.f64.data(), (int)p.f64.size(), (hipStream_t)stream);
   p.f32.clear();

@@ -279,7 +279,18 @@ class EmbraceNetMultimodal(nn.Module, _RngMixin):
             h0.record_stream(cur)
             prep[0].record_stream(cur)
         else:
-            h0, h1 = self.FFNN(x_FFNN, rng=rng), self.CNN(x_CNN, rng=rng)
+            # The two pre-networks are independent chains.  The epigenomic MLP is tiny and latency-bound, so its launches
+            # RIDE on kernels of the sequence CNN (csrc/rider.h): the forward is parked here and carried by the CNN's first
+            # kernel; its autograd node is attached after the CNN's, so its backward runs first and is carried by the CNN's
+            # BatchNorm-backward pass.  (ride_prenets = False, or a stack the fused kernels do not take: plain launches.)
+            handle = None
+            if rng is not None and getattr(self, "ride_prenets", True) and self.CNN.use_hip and T == torch.bfloat16:
+                handle = self.FFNN.prelaunch(x_FFNN, rng=rng)
+            if handle is not None:
+                h1 = self.CNN(x_CNN, rng=rng)
+                h0 = self.FFNN.attach(handle)
+            else:
+                h0, h1 = self.FFNN(x_FFNN, rng=rng), self.CNN(x_CNN, rng=rng)
         E = self.embracenet([h0, h1], availabilities=availabilities, selection_probabilities=p,
                             _device_dropout=device_dropout, _advance=False, _prep=prep)
         out = self._post_forward(E, rng, T)

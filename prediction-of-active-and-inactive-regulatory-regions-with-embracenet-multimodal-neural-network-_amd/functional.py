@@ -334,29 +334,61 @@ def _parr(tensors):
     return arr
 
 
+_RIDER_KEEP = []     # tensors a parked rider launch reads or writes: kept alive until the flush
+
+
+def rider_flush():
+    """Issue a parked rider launch on its own if no carrier took it (csrc/rider.h) and release its tensors."""
+    check(_lib.lib().emb_rider_flush(), "emb_rider_flush")
+    _RIDER_KEEP.clear()
+
+
+def _mlp_launch(x, rng, T, meta, params, park=False):
+    """Allocate the outputs of a fused MLP stack and launch it; park=True leaves the launch to the next carrier kernel of
+    the stream (the caller flushes).  Returns (x in T, weights in T, activations, masks, widths)."""
+    P = PARAM_DTYPE[T]
+    L_ = len(meta)
+    B, Fin = x.shape
+    dev = x.device
+    xc = _as(x, T)
+    Ws = [weight_as(params[2 * l], T) for l in range(L_)]
+    bs = [_as(params[2 * l + 1].detach(), P) for l in range(L_)]
+    Ns = [w.shape[0] for w in Ws]
+    hs = [torch.empty(B, n, dtype=T, device=dev) for n in Ns]
+    masks = [torch.empty(B, n, dtype=torch.uint8, device=dev) if (m[0] or m[1] > 0) else None for n, m in zip(Ns, meta)]
+    iN = (_ct.c_int * L_)(*Ns)
+    irelu = (_ct.c_int * L_)(*[int(bool(m[0])) for m in meta])
+    fdrop = (_ct.c_float * L_)(*[float(m[1]) for m in meta])
+    ilid = (_ct.c_int * L_)(*[int(m[2]) for m in meta])
+    L = _lib.lib()
+    if park:
+        check(L.emb_rider_defer(1), "emb_rider_defer")
+    try:
+        check(L.emb_mlp_fwd(ptr(xc), _parr(Ws), _parr(bs), _parr(hs), _parr(masks), iN, irelu, fdrop, ilid, L_, B, Fin,
+                            rng.seed, rng.step_val, ptr(rng.step_dev), rng.row0, DTYPE_CODE[T], stream()), "emb_mlp_fwd")
+    finally:
+        if park:
+            check(L.emb_rider_defer(0), "emb_rider_defer")
+    if park:
+        _RIDER_KEEP.extend([xc, *Ws, *bs, *hs, *[m for m in masks if m is not None]])
+    return xc, Ws, hs, masks, Ns
+
+
 class _MlpFn(torch.autograd.Function):
     """Whole Linear(+ReLU+Dropout) stack in one forward / two backward launches (csrc/mlp.hip).
     args: x, rng, T, meta (tuple of (relu, drop_p, layer_id) per layer), then W_0, b_0, W_1, b_1, ..."""
 
     @staticmethod
-    def forward(ctx, x, rng, T, meta, *params):
+    def forward(ctx, x, rng, T, meta, pre, *params):
         _lib.require_cuda(x)
         P = PARAM_DTYPE[T]
         L_ = len(meta)
-        B, Fin = x.shape
-        dev = x.device
-        xc = _as(x, T)
-        Ws = [weight_as(params[2 * l], T) for l in range(L_)]
-        bs = [_as(params[2 * l + 1].detach(), P) for l in range(L_)]
-        Ns = [w.shape[0] for w in Ws]
-        hs = [torch.empty(B, n, dtype=T, device=dev) for n in Ns]
-        masks = [torch.empty(B, n, dtype=torch.uint8, device=dev) if (m[0] or m[1] > 0) else None for n, m in zip(Ns, meta)]
-        iN = (_ct.c_int * L_)(*Ns)
-        irelu = (_ct.c_int * L_)(*[int(bool(m[0])) for m in meta])
-        fdrop = (_ct.c_float * L_)(*[float(m[1]) for m in meta])
-        ilid = (_ct.c_int * L_)(*[int(m[2]) for m in meta])
-        check(_lib.lib().emb_mlp_fwd(ptr(xc), _parr(Ws), _parr(bs), _parr(hs), _parr(masks), iN, irelu, fdrop, ilid, L_, B, Fin,
-                                     rng.seed, rng.step_val, ptr(rng.step_dev), rng.row0, DTYPE_CODE[T], stream()), "emb_mlp_fwd")
+        ctx.ride = pre is not None             # a prelaunched stack is an independent chain: its backward may ride as well
+        if pre is None:
+            pre = _mlp_launch(x, rng, T, meta, params)
+        else:                                  # launched (or parked as a rider) by mlp_prelaunch: make sure it has been issued
+            rider_flush()
+        xc, Ws, hs, masks, Ns = pre
         ctx.save_for_backward(xc, *Ws, *hs, *[m if m is not None else hs[0] for m in masks])
         ctx.ws_tag = f"mlp{int(meta[0][2])}"
         ctx.cfg = (T, L_, Ns, [bool(m[0]) for m in meta], [float(m[1]) for m in meta], [m is not None for m in masks],
@@ -384,14 +416,22 @@ class _MlpFn(torch.autograd.Function):
         ws = _workspace(dev, max(need, 1 << 22), ctx.ws_tag)
         irelu = (_ct.c_int * L_)(*[int(r) for r in relus])
         fdrop = (_ct.c_float * L_)(*drops)
-        check(_lib.lib().emb_mlp_bwd(ptr(xc), _parr(Ws), _parr(hs), _parr(masks), ptr(dy), ptr(dx), _parr(dWs), _parr(dbs), iN, irelu,
-                                     fdrop, L_, B, Fin, ptr(ws), ws.numel(), DTYPE_CODE[T], stream()), "emb_mlp_bwd")
+        if ctx.ride:                           # parked for the BatchNorm-backward pass of the conv stack (csrc/rider.h)
+            check(_lib.lib().emb_rider_defer(1), "emb_rider_defer")
+        try:
+            check(_lib.lib().emb_mlp_bwd(ptr(xc), _parr(Ws), _parr(hs), _parr(masks), ptr(dy), ptr(dx), _parr(dWs), _parr(dbs), iN, irelu,
+                                         fdrop, L_, B, Fin, ptr(ws), ws.numel(), DTYPE_CODE[T], stream()), "emb_mlp_bwd")
+        finally:
+            if ctx.ride:
+                check(_lib.lib().emb_rider_defer(0), "emb_rider_defer")
+        if ctx.ride:
+            _RIDER_KEEP.extend([xc, dy, *Ws, *hs, *[m for m in masks if m is not None]] + ([dx] if dx is not None else []))
         cast = lambda g, d: None if g is None else (g if g.dtype == d else g.to(d))
         grads = []
         for l in range(L_):
             grads += [None if sk[2 * l] is not None else cast(dWs[l], pdts[2 * l]),
                       None if sk[2 * l + 1] is not None else cast(dbs[l], pdts[2 * l + 1])]
-        return (cast(dx, xdt), None, None, None, *grads)
+        return (cast(dx, xdt), None, None, None, None, *grads)
 
 
 def mlp(x, layers, rng=None, compute_dtype=None):
@@ -408,7 +448,33 @@ def mlp(x, layers, rng=None, compute_dtype=None):
         return x
     meta = tuple((bool(relu), float(p), int(lid)) for _, _, relu, p, lid in layers)
     params = [t for w, b, *_ in layers for t in (w, b)]
-    return _MlpFn.apply(x, rng, T, meta, *params)
+    return _MlpFn.apply(x, rng, T, meta, None, *params)
+
+
+def mlp_prelaunch(x, layers, rng=None, compute_dtype=None):
+    """First half of `mlp` for a stack whose result is not needed until other, independent kernels have been launched on the
+    stream: the forward launch is PARKED and rides on the next carrier kernel (the statistics pass of a conv stack's first
+    block, csrc/rider.h), so the two chains overlap on the GPU.  Returns a handle for `mlp_attach`, or None when the stack
+    does not take the fused kernels (call `mlp` then).  Nothing may read the activations before `mlp_attach`."""
+    T = compute_dtype or x.dtype
+    rng = rng or RngState()
+    Ns = [w.shape[0] for w, *_ in layers]
+    ok = x.is_cuda and 1 <= len(layers) <= 4 and _lib.lib().emb_mlp_supported(
+        x.shape[1], (_ct.c_int * len(Ns))(*Ns), len(Ns), DTYPE_CODE[T])
+    if not ok:
+        return None
+    meta = tuple((bool(relu), float(p), int(lid)) for _, _, relu, p, lid in layers)
+    params = [t for w, b, *_ in layers for t in (w, b)]
+    with torch.no_grad():
+        pre = _mlp_launch(x, rng, T, meta, params, park=True)
+    return (x, rng, T, meta, pre, params)
+
+
+def mlp_attach(handle):
+    """Second half of `mlp_prelaunch`: builds the autograd node (created AFTER the nodes of the kernels launched in between,
+    so its backward runs before theirs and can ride on them in turn) and returns the stack's output."""
+    x, rng, T, meta, pre, params = handle
+    return _MlpFn.apply(x, rng, T, meta, pre, *params)
 
 
 class _WeightedCEFn(torch.autograd.Function):
@@ -673,6 +739,8 @@ class _ConvStackFn(torch.autograd.Function):
         ctx.save_for_backward(*saved)
         ctx.cfg = (T, int(training), B, shapes, 0 if x_codes == 2 else x_codes, bn_sync if training else None)   # (backward reads the saved channels-last image)
         ctx.sinks = tuple(grad_sink(tensors[6 * i + j], P) for i in range(n_layers) for j in range(4))
+        if _RIDER_KEEP:
+            rider_flush()                      # a parked MLP forward that no kernel of this stack carried
         return cur.reshape(B, -1)
 
     @staticmethod
@@ -707,6 +775,8 @@ class _ConvStackFn(torch.autograd.Function):
                     sync(sums)                                       # {sum dz, sum dz*xhat, rows} -> of the global batch
             grads[6 * i:6 * i + 4] = [None if sk[j] is not None else g_ for j, g_ in enumerate((dW, db, dgam, dbeta))]
             g = dx
+        if _RIDER_KEEP:
+            rider_flush()                      # a parked MLP backward that no kernel of this stack carried
         return (None, None, None, None, None, None, *grads)
 
 

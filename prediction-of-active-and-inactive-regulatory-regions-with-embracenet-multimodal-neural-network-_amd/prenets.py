@@ -51,6 +51,21 @@ class FFNN_pre(nn.Module):
                   for i in range(0, len(mods), 3)]
         return F_.mlp(x, layers, rng=rng, compute_dtype=T)
 
+    def prelaunch(self, x, rng=None):
+        """Forward whose launch is parked to ride on the sequence CNN's first kernel (functional.mlp_prelaunch); returns a
+        handle for `attach`, or None when the stack does not qualify (call the module then)."""
+        if not self.use_hip or not x.is_cuda:
+            return None
+        T = self.compute_dtype or self.model[0].weight.dtype
+        mods = list(self.model)
+        layers = [(mods[i].weight, mods[i].bias, True, float(mods[i + 2].p) if self.training else 0.0, _FFNN_LAYER_ID0 + i // 3)
+                  for i in range(0, len(mods), 3)]
+        return F_.mlp_prelaunch(x, layers, rng=rng, compute_dtype=T)
+
+    @staticmethod
+    def attach(handle):
+        return F_.mlp_attach(handle)
+
 
 class CNN_pre(nn.Module):
     def __init__(self, trial, device):

@@ -175,6 +175,43 @@ def test_philox_training_step_bf16_runs_and_learns(ea):
     assert np.isfinite(losses).all() and np.mean(losses[-5:]) < np.mean(losses[:5]) - 0.02, losses
 
 
+@pytest.mark.parametrize("mode", ["autograd", "runner"])
+def test_prenet_riders_change_nothing(ea, mode):
+    """The epigenomic MLP launches riding on kernels of the sequence CNN (csrc/rider.h, model.ride_prenets) are the same
+    computations issued inside other launches: losses, parameters and BatchNorm statistics after a few bf16 steps are
+    bit-identical to plain launches -- with a step runner (slab reductions deferred: forward AND backward ride) and with a
+    plain autograd loop (forward rides; the backward is launched on its own because its reduction is not deferred)."""
+    from embracenet_amd import optim, training
+    def run(ride):
+        model, trial, hp, F_in = build(ea, "cfg1", "rd", torch.float32)
+        model = training.prepare_model(model, DEV, "bfloat16").set_rng("philox", seed=5)
+        model.ride_prenets = ride
+        opt = optim.Adam(model.parameters(), lr=1e-3, weight_decay=1e-3)
+        model.train()
+        losses = []
+        if mode == "runner":
+            runner = training.StepRunner(model, opt, DEV)
+            table = ea.metrics.StepTable(4, DEV)
+        for k in range(4):
+            a, b, y = model_batch(f"rd/{k}", 96 if k < 3 else 40, F_in, 0.3)        # (the last batch: partial row blocks)
+            x1, x2, yy = torch.from_numpy(a).float(), torch.from_numpy(b).float(), torch.from_numpy(y)
+            if mode == "runner":
+                runner.train_step(x1, x2, yy, table)
+            else:
+                opt.zero_grad()
+                loss = ea.functional.weighted_ce(model([x1.to(DEV), x2.to(DEV)], is_training=True), yy.to(DEV))
+                loss.backward()
+                opt.step()
+                losses.append(loss.item())
+        if mode == "runner":
+            losses = table.fetch()[0].tolist()
+        return losses, {k: v.detach().cpu().clone() for k, v in model.state_dict().items()}
+    (la, sa), (lb, sb) = run(False), run(True)
+    assert la == lb, (la, lb)
+    for k in sa:
+        assert torch.equal(sa[k], sb[k]), k
+
+
 @pytest.mark.parametrize("precision", ["bfloat16", "float32"])
 def test_graph_replayed_steps_equal_eager_steps(ea, precision):
     """training.set_graph_steps: fit_multimodal replaying captured train / eval steps (one hipGraph per batch shape, ragged
