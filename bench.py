@@ -336,40 +336,47 @@ def step_accounting(wl, dims, ms_per_step, stats_csv):
                                            [hp[f"FFNN_n_units_l{i}"] for i in range(hp["FFNN_n_layers"])])) * B
     K = d0 + d1
     c0 = convs[0]
-    table = {   # kernel-name fragment -> (flops, bytes)
-        "first_kernel<2, 2, 0>": (c0["flops"], B * 4 * 256 * s + c0["x"]),                       # stats pass: loader layout in, image out
-        "first_kernel<2, 2, 1>": (c0["flops"], c0["x"] + c0["pooled"] + c0["arg"]),              # recompute + BN/ReLU/pool out
-        "first_kernel<2, 2, 2>": (c0["flops"], c0["x"] + c0["pooled"] + c0["arg"]),              # recompute + window-space sums
-        "first_kernel<2, 2, 3>": (2 * c0["flops"], c0["x"] + c0["pooled"] + c0["arg"]),          # recompute + weight gradient
-        "embrace_fwd": (2.0 * B * c * K, s * B * K + s * c * K + s * B * c + B * c),
-        "embrace_bwd": (4.0 * B * c * K, s * B * c + B * c + 2 * s * B * K + s * c * K + 4 * c * K),
-        "mlp_fwd": (ffnn, B * wl["F"] * s), "mlp_bwd": (2 * ffnn, B * wl["F"] * s),
-        "head_ce": (3 * 2.0 * B * c * 2, 2 * s * B * c),
+    # kernel class -> (name fragments of the kernels that implement it, newest first; flops; bytes).  The epigenomic MLP stack
+    # has no launch of its own on the bf16 path: its forward / backward ride on first_stats / bn_bwd_dz (csrc/rider.h), whose
+    # lines therefore carry the MLP's FLOPs and bytes as well.
+    rider = wl["dtype"] == "bfloat16"
+    mlp_f, mlp_b = (ffnn, B * wl["F"] * s), (2 * ffnn, B * wl["F"] * s)
+    table = {
+        "first_stats": (["first_stats_rider_kernel", "first_kernel<2, 2, 0>"], c0["flops"] + (mlp_f[0] if rider else 0),
+                        B * 4 * 256 * s + c0["x"] + (mlp_f[1] if rider else 0)),                # loader layout in, image out
+        "first_apply": (["first_kernel<2, 2, 1>"], c0["flops"], c0["x"] + c0["pooled"] + c0["arg"]),   # recompute + BN/ReLU/pool out
+        "first_bwd_sums": (["first_kernel<2, 2, 2>"], c0["flops"], c0["x"] + c0["pooled"] + c0["arg"]),   # recompute + window-space sums
+        "first_bwd_wgrad": (["first_kernel<2, 2, 3>"], 2 * c0["flops"], c0["x"] + c0["pooled"] + c0["arg"]),   # recompute + weight gradient
+        "embrace_fwd": (["embrace_fwd"], 2.0 * B * c * K, s * B * K + s * c * K + s * B * c + B * c),
+        "embrace_bwd": (["embrace_bwd"], 4.0 * B * c * K, s * B * c + B * c + 2 * s * B * K + s * c * K + 4 * c * K),
+        "head_ce": (["head_ce"], 3 * 2.0 * B * c * 2, 2 * s * B * c),
     }
+    if not rider:
+        table.update({"mlp_fwd": (["mlp_fwd"], *mlp_f), "mlp_bwd": (["mlp_bwd"], *mlp_b)})
     if len(convs) > 1:
         c1 = convs[1]
         table.update({
-            "conv_t_kernelIDF16bLi2": (c1["flops"], c1["x"] + c1["y"]),                           # conv-2 forward
-            "conv_t_kernelIDF16bLi4": (c1["flops"], c1["y"] + c1["x"]),                           # conv-2 input gradient
-            "conv_wgrad_direct": (c1["flops"], c1["y"] + c1["x"]),
-            "bn_relu_pool": (0.0, c1["y"] + c1["pooled"] + c1["arg"]),
-            "bn_bwd_dz": (0.0, c1["pooled"] + c1["arg"] + 2 * c1["y"]),
-            "bn_bwd_affine": (0.0, 3 * c1["y"]),
+            "conv2_fwd": (["conv_t_stream_kernel<2, 2, true>", "conv_t_kernelIDF16bLi2"], c1["flops"], c1["x"] + c1["y"]),
+            "conv2_dgrad": (["conv_t_stream_kernel<4, 1, false>", "conv_t_kernelIDF16bLi4"], c1["flops"], c1["y"] + c1["x"]),
+            "conv2_wgrad": (["conv_wgrad_stream", "conv_wgrad_direct"], c1["flops"], c1["y"] + c1["x"]),
+            "bn_relu_pool": (["bn_relu_pool"], 0.0, c1["y"] + c1["pooled"] + c1["arg"]),
+            "bn_bwd_dz": (["bn_bwd_dz"], (mlp_b[0] if rider else 0.0), c1["pooled"] + c1["arg"] + 2 * c1["y"] + (mlp_b[1] if rider else 0)),
+            "bn_bwd_affine": (["bn_bwd_affine"], 0.0, 3 * c1["y"]),
         })
     rows = {}
     if stats_csv and os.path.exists(stats_csv):
         for r in csv.DictReader(open(stats_csv)):
             rows[r["Name"]] = float(r["AverageNs"]) / 1e3
     kernels = {}
-    for frag, (fl, by) in table.items():
-        us = next((v for n, v in rows.items() if frag in n), None)
+    for cls, (frags, fl, by) in table.items():
+        us = next((v for f in frags for n, v in rows.items() if f in n), None)
         ent = dict(algorithmic_flops=fl, algorithmic_bytes=by, us_per_launch=us)
         if us:
             tf, gbs = fl / us / 1e6, by / us / 1e3
             ent.update(tflops=tf, gbs=gbs, frac=max(tf / peak_tf, gbs / peak_gbs), bound="mfma" if tf / peak_tf >= gbs / peak_gbs else "hbm")
-        kernels[frag] = ent
+        kernels[cls] = ent
     total_fl = 3.0 * (sum(cv["flops"] for cv in convs) + ffnn + 2.0 * B * c * K + 2.0 * B * c * 2)
-    total_by = sum(by for _, by in table.values())
+    total_by = sum(by for _, _, by in table.values())
     us_step = ms_per_step * 1e3
     return dict(kernels=kernels, source=os.path.basename(stats_csv) if rows else None,
                 whole_step=dict(algorithmic_flops=total_fl, algorithmic_bytes=total_by, us=us_step, tflops=total_fl / us_step / 1e6,

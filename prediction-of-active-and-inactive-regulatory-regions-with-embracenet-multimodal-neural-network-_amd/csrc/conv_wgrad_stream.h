@@ -28,7 +28,7 @@ struct WsArgs {
   const __bf16* dy;     // [B][L][Cout]
   const __bf16* x;      // [B][L][64]
   float* slab;          // [S][Cout][KK + 1]
-  int B, L, KK, Cout, pad, SB, slot, tiles_m, n_tiles, S, dbg;
+  int B, L, KK, Cout, pad, SB, slot, tiles_m, n_tiles, S;
 };
 
 // fragment of a K-major image at two independent addresses (rows r and r + 4 need not be 512 bytes apart: sequence slots)
@@ -70,7 +70,7 @@ __global__ __launch_bounds__(kWsThreads, 2) void conv_wgrad_stream_kernel(const 
   // workgroups are dealt round-robin to the 8 XCDs: the n_tiles workgroups of one slice read the same tiles, so they sit on ONE
   // XCD (its L2 fetches the tile once) when the slices divide evenly
   int nt, slice;
-  if (a.S % 8 == 0 && !(a.dbg & 4)) {
+  if (a.S % 8 == 0) {
     const int xcd = blockIdx.x & 7, j = blockIdx.x >> 3;
     nt = j % a.n_tiles;
     slice = (j / a.n_tiles) * 8 + xcd;
@@ -274,7 +274,6 @@ static int launch_wgrad_stream(const void* dy, const void* x, void* slab, int B,
   a.dy = (const __bf16*)dy; a.x = (const __bf16*)x; a.slab = (float*)slab;
   a.B = B; a.L = L; a.KK = KK; a.Cout = Cout; a.pad = pad; a.SB = t.SB; a.slot = t.slot; a.tiles_m = t.tiles_m;
   a.n_tiles = cdiv(KK, 256); a.S = S;
-  a.dbg = getenv("EMB_WS_DBG") ? atoi(getenv("EMB_WS_DBG")) : 0;
   const size_t lds = (size_t)kWsBufs * (kWsXBytes + (Cout == 32 ? 128 * 64 : 128 * 128));
   static bool attr = false;
   if (!attr) {
