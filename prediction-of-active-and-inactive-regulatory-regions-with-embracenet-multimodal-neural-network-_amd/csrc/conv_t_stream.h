@@ -8,8 +8,8 @@
 //   * the weights arrive by LDS-DMA as FRAGMENT-READY 1 KiB blocks, block (k-step ks, channel tile mt) = what the 64 lanes of
 //     a wave read for that MFMA step (lane l at byte 16 l): the permutation is in the per-lane SOURCE offset, formed once; an A
 //     fragment read is ds_read_b128 at "running block pointer + immediate";
-//   * the activation tile arrives by LDS-DMA in the padded-pitch layout the B reads want (cin * 2 + 16 bytes per row:
-//     conflict-free 16-byte row reads): LDS slot s = 64 j + lane of instruction j is (row s / (RS + 1), column s % (RS + 1)), the
+//   * the activation tile arrives by LDS-DMA in the padded-pitch layout the B reads want (cin * 2 + 32 bytes per row:
+//     conflict-free 16-byte row reads): LDS slot s = 64 j + lane of instruction j is (row s / (RS + 2), column s % (RS + 2)), the
 //     pad column and the halo rows are lanes whose offset is out of range (they write zeros);
 //   * a tap is one pitch further down: the loop over taps adds the pitch to NT address registers, everything inside a tap is
 //     an immediate.  No other address arithmetic in the loop.
@@ -35,7 +35,9 @@ template <int MT, int CPT, bool FWD>   // channel tiles per workgroup; k-steps p
 __global__ __launch_bounds__(kCtsWaves * 64, 2) void conv_t_stream_kernel(const CtsArgs a) {
   using T = __bf16;
   constexpr int NT = kCtsNT, WAVES = kCtsWaves, BN = 16 * MT, CPL = 4 * MT;
-  constexpr int RS = 4 * CPT, PS = RS + 1, PITCH = PS * 16;              // 16-byte slots per activation row: real, with pad; bytes
+  constexpr int RS = 4 * CPT, PS = RS + 2, PITCH = PS * 16;              // 16-byte slots per activation row: real, with pad; bytes
+  // (two pad slots: ds_read_b128 is served in 16-lane groups on 64 banks; with a pitch of an odd number of slots seven of eight
+  // slots of a group collide two-way -- SQ_LDS_BANK_CONFLICT 2.3 per LDS instruction cycle --, a pitch of 2 mod 4 slots is free)
   extern __shared__ __attribute__((aligned(16))) char arena[];
   const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), g = lane >> 4, r16 = lane & 15;
   const int tn = blockIdx.x / a.nblk_m, bm = blockIdx.x % a.nblk_m, col0 = tn * BN;
@@ -200,7 +202,7 @@ template <int MT> static size_t conv_t_stream_lds(int B, int L, int cin, int KK,
   if (cin % 32 != 0 || cin > 128 || cin == 96 || KK % cin != 0 || L > kCtsBT || L < 1) return 0;
   const ConvTiling t = conv_tiling_bt(B, L, pad, kCtsBT);
   if (t.tiles_t != 1) return 0;
-  const int PS = cin / 8 + 1, xrows = t.SB * t.slot + kXExtra, nxi = (xrows * PS + 63) / 64, nks = KK / 32;
+  const int PS = cin / 8 + 2, xrows = t.SB * t.slot + kXExtra, nxi = (xrows * PS + 63) / 64, nks = KK / 32;
   if (nxi > 8 * kCtsMaxXI) return 0;                                     // plan registers
   if ((long)N * KK * 2 >= 0x7fffffffL) return 0;
   const size_t lds = (size_t)nxi * 1024 + (size_t)nks * MT * 1024 + (size_t)kCtsWaves * 2 * 16 * MT * sizeof(float);

@@ -177,6 +177,9 @@ __global__ __launch_bounds__(256) void bn_finalize_kernel(const PP* __restrict__
   __shared__ double sa[256], sb[256];
   const int c = blockIdx.x, tid = threadIdx.x;
   double mean, var;
+  // everything the finalising thread needs is requested BEFORE the reduction: as dependent loads after it they added a
+  // second memory round trip to a kernel that is nothing but latency
+  const double g_c = (double)gamma[c], b_c = (double)beta[c], rm_c = (double)running_mean[c], rv_c = (double)running_var[c];
   if (count_dev != nullptr) count = *count_dev;
   if (training) {
     double a = 0, b = 0;
@@ -190,20 +193,20 @@ __global__ __launch_bounds__(256) void bn_finalize_kernel(const PP* __restrict__
     var = sb[0] / count - mean * mean;   // biased variance (normalisation); double keeps the cancellation benign
     if (var < 0) var = 0;
   } else {
-    mean = (double)running_mean[c];
-    var = (double)running_var[c];
+    mean = rm_c;
+    var = rv_c;
   }
   if (tid == 0) {
     const double invstd = 1.0 / sqrt(var + eps);
-    const double scale = (double)gamma[c] * invstd;
+    const double scale = g_c * invstd;
     stats[c] = (P)mean;
     stats[C + c] = (P)invstd;
     stats[2 * C + c] = (P)scale;
-    stats[3 * C + c] = (P)((double)beta[c] - mean * scale);
+    stats[3 * C + c] = (P)(b_c - mean * scale);
     if (training) {   // nn.BatchNorm1d: running_var uses the unbiased estimate
       const double unbiased = count > 1 ? var * count / (count - 1.0) : var;
-      running_mean[c] = (P)((1.0 - momentum) * (double)running_mean[c] + momentum * mean);
-      running_var[c] = (P)((1.0 - momentum) * (double)running_var[c] + momentum * unbiased);
+      running_mean[c] = (P)((1.0 - momentum) * rm_c + momentum * mean);
+      running_var[c] = (P)((1.0 - momentum) * rv_c + momentum * unbiased);
       if (c == 0 && num_batches_tracked != nullptr) *num_batches_tracked += 1;   // nn.BatchNorm1d bookkeeping
     }
   }
