@@ -2,6 +2,7 @@
 // convolution of the few-channel input on the matrix cores.  bf16, cin_pad == 8, odd k <= 15, L <= 256, Cout in {16, 32, 64}.
 #pragma once
 #include "common.h"
+#include "bn_inline.h"
 
 namespace emb {
 
@@ -12,13 +13,15 @@ int conv_first_blocks(int B, int L, int cin_pad, int Cout, int k);              
 // conv_first_stats: x_codes == 2 -> x is the loader's [B][4][L] bf16 tensor and nlc_out receives the [B][L][8] image.
 int conv_first_stats(const void* x, int x_codes, void* nlc_out, const void* w, const void* bias, void* partial, int* rows, int B, int L, int Cout, int k,
                      hipStream_t s);
-int conv_first_apply(const void* x, int x_codes, const void* w, const void* bias, const void* stats, void* out, uint8_t* argmax, int out_ncl,
+// fin (apply / weight-gradient pass): non-null with fin->partial set -> the BatchNorm vectors are finalised in the launch's prologue
+// from the partial rows of the preceding statistics / sums pass (bn_inline.h); no finalize launch in between.
+int conv_first_apply(const void* x, int x_codes, const void* w, const void* bias, const void* stats, const BnFinFwd* fin, void* out, uint8_t* argmax, int out_ncl,
                      float drop_p, uint64_t seed, uint64_t step_val, const uint64_t* step_dev, int64_t row0, int layer_id, int B, int L,
                      int Cout, int k, hipStream_t s);
 int conv_first_bwd_sums(const void* dout, int dout_ncl, const uint8_t* argmax, const void* x, int x_codes, const void* w, const void* bias,
                         const void* stats, float keep_scale, void* bpart, int* rows, int B, int L, int Cout, int k, hipStream_t s);
 int conv_first_bwd_wgrad(const void* dout, int dout_ncl, const uint8_t* argmax, const void* x, int x_codes, const void* w, const void* bias,
-                         const void* stats, const void* coef, float keep_scale, int training, void* slab, int* slices, int B, int L,
-                         int Cout, int k, hipStream_t s);
+                         const void* stats, const void* coef, const BnFinBwd* fin, float keep_scale, int training, void* slab, int* slices,
+                         int B, int L, int Cout, int k, hipStream_t s);
 
 }  // namespace emb

@@ -22,6 +22,7 @@
 #include "conv_first.h"
 #include "conv_tiles.h"
 #include "rider.h"
+#include "bn_inline.h"
 #include "philox.h"
 
 namespace emb {
@@ -60,6 +61,8 @@ struct FirstArgs {
   float drop_p, keep_scale;
   int ncl, training, layer_id;
   int B, L, Lp, KK, C, pad, SB, slot, tiles_m, tpb;
+  BnFinFwd fin_f;           // F_APPLY: partial != nullptr -> the statistics are finalised in this launch's prologue (bn_inline.h)
+  BnFinBwd fin_b;           // F_BWGRAD: likewise for coef / dgamma / dbeta
 };
 
 __host__ __device__ constexpr int first_plo(int t) { return t >= 9 ? (t - 8) / 2 : 0; }   // first pooling window containing t
@@ -163,6 +166,21 @@ __device__ __forceinline__ void first_body(const FirstArgs& a, const int bm) {
       if (ch < C && kk < KK) f = *reinterpret_cast<const bf16x8*>(a.w + (long)ch * KK + kk);
       wf[mt][ks] = f;
     }
+  // ---- BatchNorm vectors: from global memory, or finalised here from the producer's partial rows (bn_inline.h)
+  const float* st_src = a.stats;
+  const float* cf_src = a.coef;
+  if (MODE == F_APPLY || MODE == F_BWGRAD) {
+    double* fin_scratch = reinterpret_cast<double*>(arena);                  // the arena is not in use before the first tile
+    float* fin_out = reinterpret_cast<float*>(fin_scratch + NTHR * 4 + 2 * BN);   // [4][BN] floats
+    if (MODE == F_APPLY && a.fin_f.partial != nullptr) {
+      bn_fin_fwd<NTHR>(a.fin_f, C, fin_scratch, fin_out, bm == 0);
+      st_src = fin_out;
+    }
+    if (MODE == F_BWGRAD && a.fin_b.partial != nullptr) {
+      bn_fin_bwd<NTHR>(a.fin_b, C, fin_scratch, fin_out, bm == 0);
+      cf_src = fin_out;
+    }
+  }
   // per-channel constants with the conv bias folded in (acc = convolution without bias):
   //   F_STATS   z = acc + k0                                  k0 = bias
   //   F_APPLY   bn(z) = acc*k0 + k1                           k0 = scale, k1 = bias*scale + shift
@@ -179,15 +197,15 @@ __device__ __forceinline__ void first_body(const FirstArgs& a, const int bm) {
       if (MODE == F_STATS) {
         k0[mt][r] = bias;
       } else if (MODE == F_APPLY) {
-        k0[mt][r] = a.stats[2 * C + ch];
-        k1[mt][r] = bias * k0[mt][r] + a.stats[3 * C + ch];
+        k0[mt][r] = st_src[2 * C + ch];
+        k1[mt][r] = bias * k0[mt][r] + st_src[3 * C + ch];
       } else if (MODE == F_BSUMS) {
         k0[mt][r] = a.stats[ch] - bias;
         k1[mt][r] = a.stats[C + ch];
       } else {
         const float mean = a.stats[ch], inv = a.stats[C + ch], sc = a.stats[2 * C + ch];
-        const float bc = a.training ? -sc * a.coef[C + ch] * inv : 0.0f;
-        const float d = a.training ? sc * (a.coef[C + ch] * inv * mean - a.coef[ch]) : 0.0f;
+        const float bc = a.training ? -sc * cf_src[C + ch] * inv : 0.0f;
+        const float d = a.training ? sc * (cf_src[C + ch] * inv * mean - cf_src[ch]) : 0.0f;
         k0[mt][r] = sc;
         k1[mt][r] = bc;
         k2[mt][r] = bc * bias + d;
@@ -756,8 +774,8 @@ int conv_first_stats(const void* x, int x_codes, void* nlc_out, const void* w, c
   return first_launch<F_STATS>(a, gm, s);
 }
 
-int conv_first_apply(const void* x, int x_codes, const void* w, const void* bias, const void* stats, void* out, uint8_t* argmax,
-                     int out_ncl,
+int conv_first_apply(const void* x, int x_codes, const void* w, const void* bias, const void* stats, const BnFinFwd* fin, void* out,
+                     uint8_t* argmax, int out_ncl,
                      float drop_p, uint64_t seed, uint64_t step_val, const uint64_t* step_dev, int64_t row0, int layer_id, int B, int L,
                      int Cout, int k, hipStream_t s) {
   FirstGeom gm;
@@ -767,6 +785,7 @@ int conv_first_apply(const void* x, int x_codes, const void* w, const void* bias
   a.x = x; a.x_codes = x_codes; a.w = (const __bf16*)w; a.bias = (const float*)bias; a.stats = (const float*)stats;
   a.out = (__bf16*)out; a.argmax = argmax; a.ncl = out_ncl; a.drop_p = drop_p; a.seed = seed; a.step_val = step_val;
   a.step_dev = step_dev; a.grow0 = row0; a.layer_id = layer_id;
+  if (fin != nullptr) a.fin_f = *fin;
   return first_launch<F_APPLY>(a, gm, s);
 }
 
@@ -786,8 +805,8 @@ int conv_first_bwd_sums(const void* dout, int dout_ncl, const uint8_t* argmax, c
 
 int conv_first_bwd_wgrad(const void* dout, int dout_ncl, const uint8_t* argmax, const void* x, int x_codes, const void* w,
                          const void* bias,
-                         const void* stats, const void* coef, float keep_scale, int training, void* slab, int* slices, int B, int L,
-                         int Cout, int k, hipStream_t s) {
+                         const void* stats, const void* coef, const BnFinBwd* fin, float keep_scale, int training, void* slab, int* slices,
+                         int B, int L, int Cout, int k, hipStream_t s) {
   FirstGeom gm;
   if (!first_geom(B, L, 8, Cout, k, &gm)) return 1;
   FirstArgs a{};
@@ -795,6 +814,7 @@ int conv_first_bwd_wgrad(const void* dout, int dout_ncl, const uint8_t* argmax, 
   a.x = x; a.x_codes = x_codes; a.w = (const __bf16*)w; a.bias = (const float*)bias; a.stats = (const float*)stats;
   a.dout = (const __bf16*)dout; a.ncl = dout_ncl; a.argmax = const_cast<uint8_t*>(argmax); a.keep_scale = keep_scale;
   a.coef = (const float*)coef; a.training = training; a.slab = (float*)slab;
+  if (fin != nullptr) a.fin_b = *fin;
   *slices = gm.nblk;
   return first_launch<F_BWGRAD>(a, gm, s);
 }

@@ -641,15 +641,27 @@ static int convblock_fwd(const void* x, const void* wpack, const void* bias, con
       EMB_CHECK_LAUNCH();
       return EMB_OK;
     }
+    // local statistics in training: the apply pass finalises them itself from the statistics pass's partial rows (bn_inline.h)
+    static const bool inline_fin = [] { const char* e = getenv("EMB_BN_INLINE"); return !(e && e[0] == '0'); }();
+    BnFinFwd fin{};
+    bool inl = false;
+    if constexpr (sizeof(P) == 4) {
+      if (inline_fin && training && bn_phase == 0 && rows > 0 && rows <= 512) {
+        fin.partial = (const float*)ws; fin.rows = rows; fin.gamma = (const float*)gamma; fin.beta = (const float*)beta;
+        fin.running_mean = (float*)rmean; fin.running_var = (float*)rvar; fin.stats = (float*)stats; fin.num_batches_tracked = (long long*)nbt;
+        fin.momentum = momentum; fin.eps = eps; fin.count = (double)R;
+        inl = true;
+      }
+    }
     if (bn_phase == 2)
       bn_finalize_kernel<P, double><<<Cout, 256, 0, s>>>(bn_sums, 1, Cout, 0.0, bn_sums + 2 * Cout, (const P*)gamma, (const P*)beta,
                                                         (P*)rmean, (P*)rvar, training, momentum, eps, (P*)stats, (long long*)nbt);
-    else
+    else if (!inl)
       bn_finalize_kernel<P, P><<<Cout, 256, 0, s>>>((const P*)ws, rows, Cout, (double)R, nullptr, (const P*)gamma, (const P*)beta,
                                                    (P*)rmean, (P*)rvar, training, momentum, eps, (P*)stats, (long long*)nbt);
     EMB_CHECK_LAUNCH();
-    const int rc1 = conv_first_apply(x_img, x_codes, wpack, bias, stats, out, argmax, out_ncl, drop_p, seed, step_val, step_dev, row0, layer_id, B, L,
-                                     Cout, k, s);
+    const int rc1 = conv_first_apply(x_img, x_codes, wpack, bias, stats, inl ? &fin : nullptr, out, argmax, out_ncl, drop_p, seed, step_val, step_dev,
+                                     row0, layer_id, B, L, Cout, k, s);
     return rc1 == 1 ? EMB_ERR_ARG : rc1;
   }
   if (bn_phase != 2) {   // the convolution (stored) and its per-tile channel sums
@@ -707,19 +719,32 @@ static int convblock_bwd(const void* dout, int dout_ncl, const uint8_t* argmax, 
     EMB_CHECK_ARG((size_t)nb * 2 * Cout * sizeof(P) <= w.bwd_partial && (size_t)nb * Cout * (KK + 1) * sizeof(P) <= w.slab,
                   "emb_convblock_bwd: workspace layout too small for the fused first block");
     int rows = 0, S = 0, rc = EMB_OK;
+    static const bool inline_fin = [] { const char* e = getenv("EMB_BN_INLINE"); return !(e && e[0] == '0'); }();
+    BnFinBwd fin{};
+    bool inl = false;
     if (bn_phase != 2) {
       rc = conv_first_bwd_sums(dout, dout_ncl, argmax, x, x_codes, wpack, bias, stats, keep_scale, bpart, &rows, B, L, Cout, k, s);
       if (rc != EMB_OK) return rc == 1 ? EMB_ERR_ARG : rc;
-      bn_bwd_finalize_kernel<P, P><<<Cout, 256, 0, s>>>(bpart, rows, Cout, (double)R, nullptr, (P*)dgamma, (P*)dbeta, coef,
-                                                       bn_phase == 1 ? bn_sums : nullptr);
-      EMB_CHECK_LAUNCH();
+      if constexpr (sizeof(P) == 4) {   // local statistics: the weight-gradient pass finalises the two means itself (bn_inline.h)
+        if (inline_fin && bn_phase == 0 && rows > 0 && rows <= 512) {
+          fin.partial = (const float*)bpart; fin.rows = rows; fin.dgamma = (float*)dgamma; fin.dbeta = (float*)dbeta; fin.coef = (float*)coef;
+          fin.count = (double)R;
+          inl = true;
+        }
+      }
+      if (!inl) {
+        bn_bwd_finalize_kernel<P, P><<<Cout, 256, 0, s>>>(bpart, rows, Cout, (double)R, nullptr, (P*)dgamma, (P*)dbeta, coef,
+                                                         bn_phase == 1 ? bn_sums : nullptr);
+        EMB_CHECK_LAUNCH();
+      }
       if (bn_phase == 1) return EMB_OK;
     } else {
       bn_bwd_finalize_kernel<P, double><<<Cout, 256, 0, s>>>(bn_sums, 1, Cout, 0.0, bn_sums + 2 * Cout, (P*)nullptr, (P*)nullptr, coef,
                                                             nullptr);
       EMB_CHECK_LAUNCH();
     }
-    rc = conv_first_bwd_wgrad(dout, dout_ncl, argmax, x, x_codes, wpack, bias, stats, coef, keep_scale, training, slab, &S, B, L, Cout, k, s);
+    rc = conv_first_bwd_wgrad(dout, dout_ncl, argmax, x, x_codes, wpack, bias, stats, coef, inl ? &fin : nullptr, keep_scale, training, slab, &S, B,
+                              L, Cout, k, s);
     if (rc != EMB_OK) return rc == 1 ? EMB_ERR_ARG : rc;
     ReduceJob j{};   // slabs -> dW (torch layout, real channels) / dbias, slices summed in fixed order (reduce.hip)
     j.in = slab; j.out[0] = dW; j.out[1] = dbias; j.per = (long)Cout * (KK + 1); j.S = S; j.kind = RJ_CONV;
