@@ -9,6 +9,8 @@
 
 namespace emb {
 
+constexpr int kBnInlineMaxC = 128;   // channels of the kernels that keep the finalisation scratch in static LDS
+
 struct BnFinFwd {                // forward: sum z, sum z^2 -> mean, invstd, scale, shift (+ running statistics)
   const float* partial;          // [rows][2][C]; nullptr: the statistics are already final (read `stats`)
   const float* gamma;

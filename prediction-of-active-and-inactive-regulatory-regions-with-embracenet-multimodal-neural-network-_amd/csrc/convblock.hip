@@ -215,17 +215,14 @@ __global__ __launch_bounds__(256) void bn_finalize_kernel(const PP* __restrict__
 // ---------------------------------------------------------------------- BN + ReLU + MaxPool (+ Dropout)
 // argmax byte: bits 0-3 = offset of the maximum inside the window (first maximum wins, as torch), bit 7 = dropped.
 template <typename T, bool NCL_OUT>
-__global__ __launch_bounds__(256) void bn_relu_pool_kernel(const T* __restrict__ y, const typename AccOf<T>::type* __restrict__ stats,
-                                                           T* __restrict__ out, uint8_t* __restrict__ argmax, int B, int L,
-                                                           int Lp, int C, float drop_p, uint64_t seed, uint64_t step_val,
-                                                           const uint64_t* __restrict__ step_dev, int64_t grow0, int layer_id) {
+__device__ __forceinline__ void bn_relu_pool_item(const T* __restrict__ y, const typename AccOf<T>::type* __restrict__ stats,
+                                                  T* __restrict__ out, uint8_t* __restrict__ argmax, int B, int L,
+                                                  int Lp, int C, float drop_p, uint64_t seed, uint64_t step_val,
+                                                  const uint64_t* __restrict__ step_dev, int64_t grow0, int layer_id, const long i) {
   using Acc = typename AccOf<T>::type;
   constexpr int VEC = Elem<T>::VEC;
   using V = typename Vec16<T>::type;
   const int cv = C / VEC;
-  const long total = (long)B * Lp * cv;
-  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= total) return;
   const int c0 = (int)(i % cv) * VEC;
   const int p = (int)((i / cv) % Lp);
   const int b = (int)(i / ((long)cv * Lp));
@@ -285,6 +282,32 @@ __global__ __launch_bounds__(256) void bn_relu_pool_kernel(const T* __restrict__
   }
 }
 
+template <typename T, bool NCL_OUT>
+__global__ __launch_bounds__(256) void bn_relu_pool_kernel(const T* __restrict__ y, const typename AccOf<T>::type* __restrict__ stats,
+                                                           T* __restrict__ out, uint8_t* __restrict__ argmax, int B, int L,
+                                                           int Lp, int C, float drop_p, uint64_t seed, uint64_t step_val,
+                                                           const uint64_t* __restrict__ step_dev, int64_t grow0, int layer_id) {
+  const long total = (long)B * Lp * (C / Elem<T>::VEC);
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= total) return;
+  bn_relu_pool_item<T, NCL_OUT>(y, stats, out, argmax, B, L, Lp, C, drop_p, seed, step_val, step_dev, grow0, layer_id, i);
+}
+
+// the same pass finalising the BatchNorm statistics itself from the convolution's partial rows (bn_inline.h): a fixed number of
+// workgroups (each pays one pass over the partial rows) walk the pooled elements grid-stride
+template <bool NCL_OUT>
+__global__ __launch_bounds__(256) void bn_relu_pool_fin_kernel(const __bf16* __restrict__ y, const BnFinFwd fin, __bf16* __restrict__ out,
+                                                               uint8_t* __restrict__ argmax, int B, int L, int Lp, int C, float drop_p,
+                                                               uint64_t seed, uint64_t step_val, const uint64_t* __restrict__ step_dev,
+                                                               int64_t grow0, int layer_id) {
+  __shared__ double scratch[256 * 4 + 2 * kBnInlineMaxC];
+  __shared__ float fs[4 * kBnInlineMaxC];
+  bn_fin_fwd<256>(fin, C, scratch, fs, blockIdx.x == 0);
+  const long total = (long)B * Lp * (C / 8);
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256)
+    bn_relu_pool_item<__bf16, NCL_OUT>(y, fs, out, argmax, B, L, Lp, C, drop_p, seed, step_val, step_dev, grow0, layer_id, i);
+}
+
 // BatchNorm / pool / ReLU backward, pass 1.  One block = TT consecutive positions of one sequence, all channels.
 // The pooled gradient rows (and their argmax bytes) that can reach those positions are staged in LDS once;
 // dz[b,t,c] = sum over the <= 5 windows containing t whose argmax is t (deterministic gather, no atomics),
@@ -302,19 +325,30 @@ template <typename T, bool NCL_IN>
 __device__ __forceinline__ void bn_bwd_dz_body(const T* __restrict__ dout, const uint8_t* __restrict__ argmax,
                                                const T* __restrict__ y, const typename AccOf<T>::type* __restrict__ stats,
                                                T* __restrict__ dz_out, typename AccOf<T>::type* __restrict__ bpart, int L,
-                                               int Lp, int C, float keep_scale, int TT, int tiles_per_seq, const int bid) {
+                                               int Lp, int C, float keep_scale, int TT, int tiles_per_seq, const int bid,
+                                               const int nwg, const int nitems) {
+  // workgroup `bid` of `nwg` handles items bid, bid + nwg, ... (nwg == nitems: one item each) and writes ONE partial row
   using Acc = typename AccOf<T>::type;
   constexpr int VEC = Elem<T>::VEC;
   using V = typename Vec16<T>::type;
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  const int b = bid / tiles_per_seq, t0 = (bid % tiles_per_seq) * TT;
+  const int TX = C / VEC, TY = 256 / TX;
+  const int tx = threadIdx.x % TX, ty = threadIdx.x / TX;
+  const int c0 = tx * VEC;
+  Acc s1[VEC], s2[VEC], mean[VEC], inv[VEC], sc[VEC], sh[VEC];
+#pragma unroll
+  for (int e = 0; e < VEC; ++e) {
+    s1[e] = 0; s2[e] = 0;
+    mean[e] = stats[c0 + e]; inv[e] = stats[C + c0 + e]; sc[e] = stats[2 * C + c0 + e]; sh[e] = stats[3 * C + c0 + e];
+  }
+  for (int item = bid; item < nitems; item += nwg) {
+  if (item != bid) __syncthreads();                    // the previous item's LDS tiles are consumed
+  const int b = item / tiles_per_seq, t0 = (item % tiles_per_seq) * TT;
   const int t_end = min(L, t0 + TT);
   const int P0 = pool_plo(t0), P1 = min(Lp - 1, (t_end - 1) / 2), NP = P1 - P0 + 1;   // NP <= TT/2 + 5
   const int NPmax = TT / 2 + 5;
   T* dsm = reinterpret_cast<T*>(smem);                                   // [NPmax][C]
   uint8_t* asm_ = reinterpret_cast<uint8_t*>(smem) + (size_t)NPmax * C * sizeof(T);   // [NPmax][C]
-  const int TX = C / VEC, TY = 256 / TX;
-  const int tx = threadIdx.x % TX, ty = threadIdx.x / TX;
   if (NP > 0) {
     const long nlc0 = ((long)b * Lp + P0) * C;
     const int nvec = NP * C / VEC;
@@ -336,13 +370,6 @@ __device__ __forceinline__ void bn_bwd_dz_body(const T* __restrict__ dout, const
     }
   }
   __syncthreads();
-  const int c0 = tx * VEC;
-  Acc s1[VEC], s2[VEC], mean[VEC], inv[VEC], sc[VEC], sh[VEC];
-#pragma unroll
-  for (int e = 0; e < VEC; ++e) {
-    s1[e] = 0; s2[e] = 0;
-    mean[e] = stats[c0 + e]; inv[e] = stats[C + c0 + e]; sc[e] = stats[2 * C + c0 + e]; sh[e] = stats[3 * C + c0 + e];
-  }
   if (ty < TY) {
     for (int t = t0 + ty; t < t_end; t += TY) {
       Acc dz[VEC];
@@ -375,6 +402,7 @@ __device__ __forceinline__ void bn_bwd_dz_body(const T* __restrict__ dout, const
       *reinterpret_cast<V*>(dz_out + r * C + c0) = o;
     }
   }
+  }   // items
   __syncthreads();   // LDS is reused for the block reduction
   // [TY][2C + 1]: the element-wise stores of a 32-lane group go to (ty, tx) = 8 x 4 rows/columns; with a pitch of 2C words
   // (a multiple of the 32 store banks) all eight ty collided, the odd pitch spreads them over the banks (PMC: conflict
@@ -400,8 +428,8 @@ template <typename T, bool NCL_IN>
 __global__ __launch_bounds__(256) void bn_bwd_dz_kernel(const T* __restrict__ dout, const uint8_t* __restrict__ argmax,
                                                         const T* __restrict__ y, const typename AccOf<T>::type* __restrict__ stats,
                                                         T* __restrict__ dz_out, typename AccOf<T>::type* __restrict__ bpart, int L,
-                                                        int Lp, int C, float keep_scale, int TT, int tiles_per_seq) {
-  bn_bwd_dz_body<T, NCL_IN>(dout, argmax, y, stats, dz_out, bpart, L, Lp, C, keep_scale, TT, tiles_per_seq, (int)blockIdx.x);
+                                                        int Lp, int C, float keep_scale, int TT, int tiles_per_seq, int nwg, int nitems) {
+  bn_bwd_dz_body<T, NCL_IN>(dout, argmax, y, stats, dz_out, bpart, L, Lp, C, keep_scale, TT, tiles_per_seq, (int)blockIdx.x, nwg, nitems);
 }
 
 // the gather pass carrying the backward of the epigenomic MLP stack as its first `nr` workgroups (rider.h)
@@ -409,14 +437,14 @@ template <bool NCL_IN>
 __global__ __launch_bounds__(256) void bn_bwd_dz_rider_kernel(const __bf16* __restrict__ dout, const uint8_t* __restrict__ argmax,
                                                               const __bf16* __restrict__ y, const float* __restrict__ stats,
                                                               __bf16* __restrict__ dz_out, float* __restrict__ bpart, int L, int Lp, int C,
-                                                              float keep_scale, int TT, int tiles_per_seq, const MlpBwdArgs<__bf16> ba,
-                                                              const MmBwdLayout bl, const int nr) {
+                                                              float keep_scale, int TT, int tiles_per_seq, int nwg, int nitems,
+                                                              const MlpBwdArgs<__bf16> ba, const MmBwdLayout bl, const int nr) {
   if ((int)blockIdx.x < nr) {
     extern __shared__ __attribute__((aligned(16))) char rider_arena[];
     if (threadIdx.x < 64) mlp_bwd_mfma_body(ba, bl, (int)blockIdx.x, rider_arena);
     return;
   }
-  bn_bwd_dz_body<__bf16, NCL_IN>(dout, argmax, y, stats, dz_out, bpart, L, Lp, C, keep_scale, TT, tiles_per_seq, (int)blockIdx.x - nr);
+  bn_bwd_dz_body<__bf16, NCL_IN>(dout, argmax, y, stats, dz_out, bpart, L, Lp, C, keep_scale, TT, tiles_per_seq, (int)blockIdx.x - nr, nwg, nitems);
 }
 
 // finalise dgamma / dbeta and the two per-channel means the apply pass needs: coef[0][c] = mean(dz), coef[1][c] = mean(dz*xhat)
@@ -504,6 +532,39 @@ __global__ __launch_bounds__(256) void bn_bwd_affine_kernel(const T* __restrict_
 #pragma unroll
     for (int e = 0; e < VEC; ++e) o[e] = (T)(A[e] * (Acc)dzv[e] + Bc[e] * (Acc)yv[e] + D[e]);
     *reinterpret_cast<V*>(dy + off) = o;
+  }
+}
+
+// the same pass finalising dgamma / dbeta and the two means itself from the gather pass's partial rows (bn_inline.h); a fixed
+// number of workgroups walk the row blocks grid-stride
+__global__ __launch_bounds__(256) void bn_bwd_affine_fin_kernel(const __bf16* __restrict__ y, const float* __restrict__ stats, const BnFinBwd fin,
+                                                                __bf16* __restrict__ dy, int R, int C, int training, int rows_per_block) {
+  __shared__ double scratch[256 * 4 + 2 * kBnInlineMaxC];
+  __shared__ float fc[2 * kBnInlineMaxC];
+  bn_fin_bwd<256>(fin, C, scratch, fc, blockIdx.x == 0);
+  const int TX = C / 8, TY = 256 / TX;
+  const int tx = threadIdx.x % TX, ty = threadIdx.x / TX;
+  if (ty >= TY) return;
+  const int c0 = tx * 8;
+  float A[8], Bc[8], D[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    const float mean = stats[c0 + e], inv = stats[C + c0 + e], sc = stats[2 * C + c0 + e];
+    A[e] = sc;
+    Bc[e] = training ? -sc * fc[C + c0 + e] * inv : 0.0f;
+    D[e] = training ? sc * (fc[C + c0 + e] * inv * mean - fc[c0 + e]) : 0.0f;
+  }
+  for (int r0 = blockIdx.x * rows_per_block; r0 < R; r0 += gridDim.x * rows_per_block) {
+    const int r_end = min(R, r0 + rows_per_block);
+    for (int r = r0 + ty; r < r_end; r += TY) {
+      const long off = (long)r * C + c0;
+      const bf16x8 dzv = *reinterpret_cast<const bf16x8*>(dy + off);
+      const bf16x8 yv = *reinterpret_cast<const bf16x8*>(y + off);
+      bf16x8 o;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) o[e] = (__bf16)(A[e] * (float)dzv[e] + Bc[e] * (float)yv[e] + D[e]);
+      *reinterpret_cast<bf16x8*>(dy + off) = o;
+    }
   }
 }
 
@@ -678,6 +739,23 @@ static int convblock_fwd(const void* x, const void* wpack, const void* bias, con
       EMB_CHECK_LAUNCH();
       return EMB_OK;
     }
+    if constexpr (sizeof(T) == 2) {   // bf16, local statistics: the pooling pass finalises them itself (bn_inline.h)
+      static const bool inline_fin = [] { const char* e = getenv("EMB_BN_INLINE"); return !(e && e[0] == '0'); }();
+      if (inline_fin && training && tiles_m > 0 && tiles_m <= 512 && Cout <= kBnInlineMaxC && Cout % 8 == 0) {
+        BnFinFwd fin{};
+        fin.partial = (const float*)ws; fin.rows = tiles_m; fin.gamma = (const float*)gamma; fin.beta = (const float*)beta;
+        fin.running_mean = (float*)rmean; fin.running_var = (float*)rvar; fin.stats = (float*)stats; fin.num_batches_tracked = (long long*)nbt;
+        fin.momentum = momentum; fin.eps = eps; fin.count = (double)R;
+        const long total = (long)B * Lp * (Cout / 8);
+        const int want = (int)((total + 255) / 256), grid = want < 768 ? want : 768;   // three workgroups per CU (swept 512 .. 2048)
+        if (out_ncl)
+          bn_relu_pool_fin_kernel<true><<<grid, 256, 0, s>>>((const __bf16*)y, fin, (__bf16*)out, argmax, B, L, Lp, Cout, drop_p, seed, step_val, step_dev, row0, layer_id);
+        else
+          bn_relu_pool_fin_kernel<false><<<grid, 256, 0, s>>>((const __bf16*)y, fin, (__bf16*)out, argmax, B, L, Lp, Cout, drop_p, seed, step_val, step_dev, row0, layer_id);
+        EMB_CHECK_LAUNCH();
+        return EMB_OK;
+      }
+    }
     bn_finalize_kernel<P, P><<<Cout, 256, 0, s>>>((const P*)ws, tiles_m, Cout, (double)R, nullptr, (const P*)gamma, (const P*)beta,
                                                  (P*)rmean, (P*)rvar, training, momentum, eps, (P*)stats, (long long*)nbt);
   } else {
@@ -754,11 +832,17 @@ static int convblock_bwd(const void* dout, int dout_ncl, const uint8_t* argmax, 
   {   // dgamma / dbeta are defined in eval mode too (x-hat then uses the running statistics)
     const int TT = w.rows_per_block, tiles_per_seq = cdiv(L, TT);
     const int TY = 256 / (Cout / VEC);
+    bool affine_done = false;
     if (bn_phase != 2) {   // dz into the dy buffer + the per-block channel sums
       size_t sm = (size_t)(TT / 2 + 5) * Cout * (sizeof(T) + 1);
       const size_t sm_red = (size_t)TY * (2 * Cout + 1) * sizeof(P);
       if (sm_red > sm) sm = sm_red;
       sm = (sm + 15) & ~(size_t)15;
+      // bf16, local statistics: the gather pass runs as at most 512 workgroups (one partial row each) and the elementwise
+      // pass below finalises dgamma / dbeta / the two means itself from those rows (bn_inline.h): no finalize launch
+      static const bool inline_fin = [] { const char* e = getenv("EMB_BN_INLINE"); return !(e && e[0] == '0'); }();
+      const bool inl = sizeof(T) == 2 && inline_fin && bn_phase == 0 && Cout <= kBnInlineMaxC && Cout % 8 == 0;
+      const int nitems = w.nblk_bwd, nwg = inl && nitems > 512 ? 512 : nitems;
       Rider rd;
       bool carried = false;
       if constexpr (sizeof(T) == 2) {   // a parked MLP backward of this stream rides along (rider.h)
@@ -771,30 +855,45 @@ static int convblock_bwd(const void* dout, int dout_ncl, const uint8_t* argmax, 
             attr = true;
           }
           if (dout_ncl)
-            bn_bwd_dz_rider_kernel<true><<<w.nblk_bwd + rd.nwg, 256, sm2, s>>>((const T*)dout, argmax, (const T*)y, (const P*)stats, (T*)dy, bpart, L, Lp, Cout, keep_scale, TT, tiles_per_seq, rd.ba, rd.bl, rd.nwg);
+            bn_bwd_dz_rider_kernel<true><<<nwg + rd.nwg, 256, sm2, s>>>((const T*)dout, argmax, (const T*)y, (const P*)stats, (T*)dy, bpart, L, Lp, Cout, keep_scale, TT, tiles_per_seq, nwg, nitems, rd.ba, rd.bl, rd.nwg);
           else
-            bn_bwd_dz_rider_kernel<false><<<w.nblk_bwd + rd.nwg, 256, sm2, s>>>((const T*)dout, argmax, (const T*)y, (const P*)stats, (T*)dy, bpart, L, Lp, Cout, keep_scale, TT, tiles_per_seq, rd.ba, rd.bl, rd.nwg);
+            bn_bwd_dz_rider_kernel<false><<<nwg + rd.nwg, 256, sm2, s>>>((const T*)dout, argmax, (const T*)y, (const P*)stats, (T*)dy, bpart, L, Lp, Cout, keep_scale, TT, tiles_per_seq, nwg, nitems, rd.ba, rd.bl, rd.nwg);
           carried = true;
         }
       }
       if (carried) {
       } else if (dout_ncl)
-        bn_bwd_dz_kernel<T, true><<<w.nblk_bwd, 256, sm, s>>>((const T*)dout, argmax, (const T*)y, (const P*)stats, (T*)dy, bpart, L, Lp, Cout, keep_scale, TT, tiles_per_seq);
+        bn_bwd_dz_kernel<T, true><<<nwg, 256, sm, s>>>((const T*)dout, argmax, (const T*)y, (const P*)stats, (T*)dy, bpart, L, Lp, Cout, keep_scale, TT, tiles_per_seq, nwg, nitems);
       else
-        bn_bwd_dz_kernel<T, false><<<w.nblk_bwd, 256, sm, s>>>((const T*)dout, argmax, (const T*)y, (const P*)stats, (T*)dy, bpart, L, Lp, Cout, keep_scale, TT, tiles_per_seq);
+        bn_bwd_dz_kernel<T, false><<<nwg, 256, sm, s>>>((const T*)dout, argmax, (const T*)y, (const P*)stats, (T*)dy, bpart, L, Lp, Cout, keep_scale, TT, tiles_per_seq, nwg, nitems);
       EMB_CHECK_LAUNCH();
-      bn_bwd_finalize_kernel<P, P><<<Cout, 256, 0, s>>>(bpart, w.nblk_bwd, Cout, (double)R, nullptr, (P*)dgamma, (P*)dbeta, coef,
-                                                       bn_phase == 1 ? bn_sums : nullptr);
-      EMB_CHECK_LAUNCH();
+      if constexpr (sizeof(T) == 2) {
+        if (inl) {
+          BnFinBwd fin{};
+          fin.partial = (const float*)bpart; fin.rows = nwg; fin.dgamma = (float*)dgamma; fin.dbeta = (float*)dbeta; fin.coef = (float*)coef;
+          fin.count = (double)R;
+          const int rpb = TY * 8, nblk = cdiv(R, rpb);
+          bn_bwd_affine_fin_kernel<<<nblk < 512 ? nblk : 512, 256, 0, s>>>((const __bf16*)y, (const float*)stats, fin, (__bf16*)dy, R, Cout, training, rpb);
+          EMB_CHECK_LAUNCH();
+          affine_done = true;
+        }
+      }
+      if (!affine_done) {
+        bn_bwd_finalize_kernel<P, P><<<Cout, 256, 0, s>>>(bpart, nwg, Cout, (double)R, nullptr, (P*)dgamma, (P*)dbeta, coef,
+                                                         bn_phase == 1 ? bn_sums : nullptr);
+        EMB_CHECK_LAUNCH();
+      }
       if (bn_phase == 1) return EMB_OK;
     } else {
       bn_bwd_finalize_kernel<P, double><<<Cout, 256, 0, s>>>(bn_sums, 1, Cout, 0.0, bn_sums + 2 * Cout, (P*)nullptr, (P*)nullptr, coef,
                                                             nullptr);
       EMB_CHECK_LAUNCH();
     }
-    const int rpb = TY * 8;   // rows per block of the elementwise pass
-    bn_bwd_affine_kernel<T><<<cdiv(R, rpb), 256, 0, s>>>((const T*)y, (const P*)stats, coef, (T*)dy, R, Cout, training, rpb);
-    EMB_CHECK_LAUNCH();
+    if (!affine_done) {
+      const int rpb = TY * 8;   // rows per block of the elementwise pass
+      bn_bwd_affine_kernel<T><<<cdiv(R, rpb), 256, 0, s>>>((const T*)y, (const P*)stats, coef, (T*)dy, R, Cout, training, rpb);
+      EMB_CHECK_LAUNCH();
+    }
   }
   // wgrad: reduction over all B*L rows, split into slices whose partial slabs are reduced in order
   {
