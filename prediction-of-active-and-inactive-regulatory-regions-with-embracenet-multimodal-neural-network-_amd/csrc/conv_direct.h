@@ -45,5 +45,9 @@ int launch_conv_direct(int dtype, bool fwd, const void* x, const void* w, const 
 int launch_conv_wgrad_direct(int dtype, const void* dy, const void* x, void* slab, int B, int L, int cin, int KK, int Cout, int pad,
                              int S, hipStream_t s);
 int conv_wgrad_slices(int B, int L, int cin, int pad, int KK, int Cout, int dtype);
+// bf16: weight gradient (slab[S][Cout][k*cin+1]) and input gradient (dx = conv of dy with the tap-flipped weights) in one launch;
+// EMB_OK, a negative error, or 1 when the shapes do not qualify (S = conv_wgrad_slices(...))
+int launch_conv_bwd_dual(const void* dy, const void* x, void* slab, const void* wflip, void* dx, int B, int L, int cin, int k, int Cout,
+                         int pad, int S, hipStream_t s);
 
 }  // namespace emb

@@ -735,6 +735,50 @@ template <typename T> static int launch_wgrad_t(const void* dy, const void* x, v
   return launch_wgrad<T, 32>(dy, x, slab, B, L, cin, KK, Cout, pad, S, s);
 }
 
+// ---- weight gradient and input gradient of a stored-activation block in ONE launch (bf16 streaming kernels): both consume dy and
+// neither reads the other's output.  The first workgroups run the weight-gradient body, the rest the input-gradient body; as
+// the weight-gradient workgroups retire at different times the input-gradient workgroups fill the CUs behind them, so the two
+// tails overlap and one launch boundary disappears.
+template <int MIW, int CPT>
+__global__ __launch_bounds__(512, 2) void conv_bwd_dual_kernel(const WsArgs wa, const CtsArgs ca, const int nws) {
+  if ((int)blockIdx.x < nws) conv_wgrad_stream_body<MIW>(wa, (int)blockIdx.x);
+  else conv_t_stream_body<4, CPT, false>(ca, (int)blockIdx.x - nws);
+}
+
+// returns EMB_OK when the dual launch ran, 1 when the shapes / pointers do not qualify (the caller launches the two kernels)
+int launch_conv_bwd_dual(const void* dy, const void* x, void* slab, const void* wflip, void* dx, int B, int L, int cin, int k, int Cout,
+                         int pad, int S, hipStream_t s) {
+  static const bool on = [] { const char* e = getenv("EMB_CONV_DUAL"); return !(e && e[0] == '0'); }();
+  const int KK = k * cin, KKd = k * Cout;
+  if (!on || !wgrad_stream_enabled() || cin != 64 || !conv_wgrad_stream_shape_ok(B, L, cin, KK, Cout, pad) || !aligned16(dy) || !aligned16(x) ||
+      !aligned16(wflip) || !aligned16(dx) || S > conv_tiling(B, L, pad).tiles_m)
+    return 1;
+  if (cdiv(KKd, 32) <= kWRegSteps) return 1;                       // (tiny reductions keep the weights-in-registers kernel)
+  const size_t lds_d = conv_t_stream_lds<4>(B, L, Cout, KKd, cin, pad);
+  if (lds_d == 0) return 1;
+  WsArgs wa{};
+  const size_t lds_w = wgrad_stream_fill(wa, dy, x, slab, B, L, KK, Cout, pad, S);
+  const ConvTiling t = conv_tiling_bt(B, L, pad, kCtsBT);
+  CtsArgs ca{};
+  ca.x = (const __bf16*)dy; ca.w = (const __bf16*)wflip; ca.bias = nullptr; ca.out = (__bf16*)dx; ca.partial = nullptr;
+  ca.B = B; ca.L = L; ca.cin = Cout; ca.KK = KKd; ca.N = cin; ca.pad = pad; ca.SB = t.SB; ca.slot = t.slot; ca.tiles_m = t.tiles_m;
+  ca.taps = k;
+  ca.tpb = cdiv(t.tiles_m, 256) < 1 ? 1 : cdiv(t.tiles_m, 256);
+  ca.nblk_m = cdiv(t.tiles_m, ca.tpb);
+  const int nws = wa.n_tiles * S, nct = ca.nblk_m;               // (cin = 64 = 16 * MT: one column tile)
+  const size_t lds = lds_w > lds_d ? lds_w : lds_d;
+  static bool attr = false;
+  if (!attr) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_bwd_dual_kernel<2, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_bwd_dual_kernel<4, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    attr = true;
+  }
+  if (Cout == 32) conv_bwd_dual_kernel<2, 1><<<nws + nct, 512, lds, s>>>(wa, ca, nws);
+  else conv_bwd_dual_kernel<4, 2><<<nws + nct, 512, lds, s>>>(wa, ca, nws);
+  EMB_CHECK_LAUNCH();
+  return EMB_OK;
+}
+
 int launch_conv_wgrad_direct(int dtype, const void* dy, const void* x, void* slab, int B, int L, int cin, int KK, int Cout, int pad,
                              int S, hipStream_t s) {
   if (dtype == EMB_BF16 && wgrad_stream_enabled() && conv_wgrad_stream_shape_ok(B, L, cin, KK, Cout, pad) && aligned16(dy) && aligned16(x) &&

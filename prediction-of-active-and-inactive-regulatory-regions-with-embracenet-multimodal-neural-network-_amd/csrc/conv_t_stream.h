@@ -32,7 +32,7 @@ struct CtsArgs {
 };
 
 template <int MT, int CPT, bool FWD>   // channel tiles per workgroup; k-steps per tap (cin = 32 * CPT)
-__global__ __launch_bounds__(kCtsWaves * 64, 2) void conv_t_stream_kernel(const CtsArgs a) {
+__device__ __forceinline__ void conv_t_stream_body(const CtsArgs& a, const int block) {
   using T = __bf16;
   constexpr int NT = kCtsNT, WAVES = kCtsWaves, BN = 16 * MT, CPL = 4 * MT;
   constexpr int RS = 4 * CPT, PS = RS + 2, PITCH = PS * 16;              // 16-byte slots per activation row: real, with pad; bytes
@@ -40,7 +40,7 @@ __global__ __launch_bounds__(kCtsWaves * 64, 2) void conv_t_stream_kernel(const 
   // slots of a group collide two-way -- SQ_LDS_BANK_CONFLICT 2.3 per LDS instruction cycle --, a pitch of 2 mod 4 slots is free)
   extern __shared__ __attribute__((aligned(16))) char arena[];
   const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), g = lane >> 4, r16 = lane & 15;
-  const int tn = blockIdx.x / a.nblk_m, bm = blockIdx.x % a.nblk_m, col0 = tn * BN;
+  const int tn = block / a.nblk_m, bm = block % a.nblk_m, col0 = tn * BN;
   const int tm_begin = bm * a.tpb, tm_end = min(a.tiles_m, tm_begin + a.tpb);
   const int L = a.L, SB = a.SB, slot = a.slot, N = a.N, KK = a.KK;
   const int nks = KK / 32, xrows = SB * slot + kXExtra;
@@ -195,6 +195,11 @@ __global__ __launch_bounds__(kCtsWaves * 64, 2) void conv_t_stream_kernel(const 
       }
     }
   }
+}
+
+template <int MT, int CPT, bool FWD>
+__global__ __launch_bounds__(kCtsWaves * 64, 2) void conv_t_stream_kernel(const CtsArgs a) {
+  conv_t_stream_body<MT, CPT, FWD>(a, (int)blockIdx.x);
 }
 
 // LDS bytes of the streaming kernel, 0 when the shape does not qualify

@@ -57,7 +57,7 @@ __device__ __forceinline__ void dma16_opaque(const void* origin, long bytes, uin
 }
 
 template <int MIW>   // Cout = 16 * MIW: 2 (dy rows of 64 bytes) or 4 (128 bytes)
-__global__ __launch_bounds__(kWsThreads, 2) void conv_wgrad_stream_kernel(const WsArgs a) {
+__device__ __forceinline__ void conv_wgrad_stream_body(const WsArgs& a, const int block) {
   constexpr int DYROW = 32 * MIW;                          // bytes per dy row
   constexpr int DYB = 128 * DYROW;                         // dy image: 128 rows
   constexpr int NDY = DYB / 1024 / 8;                      // dy LDS-DMA instructions per wave and tile (1 or 2)
@@ -71,12 +71,12 @@ __global__ __launch_bounds__(kWsThreads, 2) void conv_wgrad_stream_kernel(const 
   // XCD (its L2 fetches the tile once) when the slices divide evenly
   int nt, slice;
   if (a.S % 8 == 0) {
-    const int xcd = blockIdx.x & 7, j = blockIdx.x >> 3;
+    const int xcd = block & 7, j = block >> 3;
     nt = j % a.n_tiles;
     slice = (j / a.n_tiles) * 8 + xcd;
   } else {
-    nt = blockIdx.x % a.n_tiles;
-    slice = blockIdx.x / a.n_tiles;
+    nt = block % a.n_tiles;
+    slice = block / a.n_tiles;
   }
   const int L = a.L, SB = a.SB, slot = a.slot, n0 = nt * 256;
   const int per = (a.tiles_m + a.S - 1) / a.S, tm_begin = slice * per, tm_end = min(a.tiles_m, tm_begin + per);
@@ -254,6 +254,11 @@ __global__ __launch_bounds__(kWsThreads, 2) void conv_wgrad_stream_kernel(const 
   }
 }
 
+template <int MIW>
+__global__ __launch_bounds__(kWsThreads, 2) void conv_wgrad_stream_kernel(const WsArgs a) {
+  conv_wgrad_stream_body<MIW>(a, (int)blockIdx.x);
+}
+
 // shapes the streaming kernel takes (pointer alignment is checked at launch)
 inline bool conv_wgrad_stream_shape_ok(int B, int L, int cin, int KK, int Cout, int pad) {
   if (cin != 64 || (Cout != 32 && Cout != 64) || L > kConvBT || L < 1 || KK % 64 != 0 || KK < 64) return false;
@@ -268,13 +273,17 @@ inline int conv_wgrad_stream_slices(int B, int L, int KK, int pad) {
   return S < 1 ? 1 : S;
 }
 
-static int launch_wgrad_stream(const void* dy, const void* x, void* slab, int B, int L, int KK, int Cout, int pad, int S, hipStream_t s) {
+static size_t wgrad_stream_fill(WsArgs& a, const void* dy, const void* x, void* slab, int B, int L, int KK, int Cout, int pad, int S) {
   const ConvTiling t = conv_tiling(B, L, pad);
-  WsArgs a{};
   a.dy = (const __bf16*)dy; a.x = (const __bf16*)x; a.slab = (float*)slab;
   a.B = B; a.L = L; a.KK = KK; a.Cout = Cout; a.pad = pad; a.SB = t.SB; a.slot = t.slot; a.tiles_m = t.tiles_m;
   a.n_tiles = cdiv(KK, 256); a.S = S;
-  const size_t lds = (size_t)kWsBufs * (kWsXBytes + (Cout == 32 ? 128 * 64 : 128 * 128));
+  return (size_t)kWsBufs * (kWsXBytes + (Cout == 32 ? 128 * 64 : 128 * 128));   // dynamic LDS bytes
+}
+
+static int launch_wgrad_stream(const void* dy, const void* x, void* slab, int B, int L, int KK, int Cout, int pad, int S, hipStream_t s) {
+  WsArgs a{};
+  const size_t lds = wgrad_stream_fill(a, dy, x, slab, B, L, KK, Cout, pad, S);
   static bool attr = false;
   if (!attr) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wgrad_stream_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);

@@ -896,9 +896,17 @@ static int convblock_bwd(const void* dout, int dout_ncl, const uint8_t* argmax, 
     }
   }
   // wgrad: reduction over all B*L rows, split into slices whose partial slabs are reduced in order
+  bool dual = false;   // weight and input gradient in one launch (bf16 streaming kernels, conv_direct.hip)
   {
     int S = conv_wgrad_slices(B, L, cin_pad, pad, KK, Cout, dtype_code<T>());
-    int rc = launch_conv_wgrad_direct(dtype_code<T>(), dy, x, slab, B, L, cin_pad, KK, Cout, pad, S, s);
+    int rc = 1;
+    if constexpr (sizeof(T) == 2) {
+      if (dx != nullptr && wflip != nullptr) {
+        rc = launch_conv_bwd_dual(dy, x, slab, wflip, dx, B, L, cin_pad, k, Cout, pad, S, s);
+        dual = rc == EMB_OK;
+      }
+    }
+    if (rc == 1) rc = launch_conv_wgrad_direct(dtype_code<T>(), dy, x, slab, B, L, cin_pad, KK, Cout, pad, S, s);
     if (rc == 1) {
       const int tiles_n = cdiv(KK + 1, CW::BN), tiles = cdiv(Cout, CW::BM) * tiles_n;
       const int vec_dy = (Cout % VEC == 0) && aligned16(dy), vec_x = (cin_pad % VEC == 0) && aligned16(x);
@@ -921,7 +929,7 @@ static int convblock_bwd(const void* dout, int dout_ncl, const uint8_t* argmax, 
     const int rcr = reduce_submit(j, sizeof(P) == 8, s);
     if (rcr != EMB_OK) return rcr;
   }
-  if (dx != nullptr) {   // dgrad: the same conv-view GEMM on dy with flipped taps
+  if (dx != nullptr && !dual) {   // dgrad: the same conv-view GEMM on dy with flipped taps
     int rc = launch_conv_direct(dtype_code<T>(), false, dy, wflip, nullptr, dx, nullptr, nullptr, B, L, Cout, k * Cout, cin_pad, pad, s);
     if (rc == 1) {
       if (cin_pad >= 64) rc = launch_conv_gemm<typename ConvCfg<T>::F64, false>(dy, wflip, nullptr, dx, nullptr, R, L, Cout, k * Cout, cin_pad, pad, s);
