@@ -367,6 +367,9 @@ def step_accounting(wl, dims, ms_per_step, stats_csv):
     if stats_csv and os.path.exists(stats_csv):
         for r in csv.DictReader(open(stats_csv)):
             rows[r["Name"]] = float(r["AverageNs"]) / 1e3
+    if any("conv_bwd_dual_kernel" in n for n in rows) and "conv2_wgrad" in table:   # one launch for both gradients of block 2
+        (_, f1, b1), (_, f2, b2) = table.pop("conv2_wgrad"), table.pop("conv2_dgrad")
+        table["conv2_wgrad+dgrad"] = (["conv_bwd_dual_kernel"], f1 + f2, b1 + b2)
     kernels = {}
     for cls, (frags, fl, by) in table.items():
         us = next((v for f in frags for n, v in rows.items() if f in n), None)
