@@ -448,14 +448,18 @@ def main():
     F = ea.functional
     model.train()
     ticks = training.fused_ticks(model, opt, device)      # RNG step + optimizer step advance inside the loss kernel
-    # N > 1: every gradient is a view of ONE flat buffer that the backward kernels write directly, so the
-    # data-parallel reduction is a single in-place RCCL all-reduce.  Two trailing slots carry the NEXT step's
-    # local (positives, rows): the global class counts a step needs before its loss are thus
-    # reduced one step ahead inside the gradient collective (labels are known when a batch is staged).
-    flat = D.FlatGrads(model.parameters(), extra=2) if dist_path else None
+    # N > 1: every gradient is a view of one of TWO flat buffers that the backward kernels write directly (the same
+    # dist.BucketedFlatGrads the harness's StepRunner uses): the bucket of the fusion layer and the head is all-reduced
+    # asynchronously as soon as the fusion backward is enqueued -- behind ~100 us of pre-network backward --, the
+    # pre-network bucket after the backward.  Two trailing slots of the second bucket carry the NEXT step's local
+    # (positives, rows): the global class counts a step needs before its loss are thus reduced one step ahead
+    # inside the gradient collective (labels are known when a batch is staged).
+    flat = D.BucketedFlatGrads(model, extra=2) if dist_path else None
     local_counts = F.count_labels(y).to(torch.float32) if dist_path else None
 
     fused_loss = (not args.no_fused_loss) and model.fused_loss_ready(B)
+    overlap = {"early": True}   # first bucket's all-reduce issued from inside the backward (off when the backward is captured
+                                # in a graph that must not contain collectives)
 
     def fwd_bwd():
         if flat is None:
@@ -469,14 +473,22 @@ def main():
             _, dlogits = F.weighted_ce_with_grad(out, y, class_counts=counts, global_counts=dist_path, confusion=conf_slot,
                                                  loss_out=loss_slot, ticks=ticks)
         F.reduce_defer(True)                              # the weight-gradient slabs of the backward are queued: one process ->
-        out.backward(dlogits)                             # the optimizer launch sums them; N > 1 -> one reduction launch, since
-        F.reduce_defer(False)                             # the all-reduce needs finished gradients
+        if dist_path and overlap["early"]:                # the optimizer launch sums them; N > 1 -> reduced before each
+            def early():                                  # all-reduce, which needs finished gradients
+                F.reduce_flush()                          # (head + fusion slabs)
+                flat.allreduce_early()
+            F.set_after_embrace_backward(early)
+        try:
+            out.backward(dlogits)
+        finally:
+            F.set_after_embrace_backward(None)
+            F.reduce_defer(False)
         if dist_path:
-            F.reduce_flush()
+            F.reduce_flush()                              # (pre-network slabs)
 
     def reduce_grads():
         flat.extra.copy_(local_counts)                    # next batch's labels (synthetic: the same batch)
-        flat.allreduce()
+        flat.finish()                                     # waits for the first bucket, reduces the second
         counts.copy_(flat.extra.round().to(torch.int64))
 
     if dist_path:                                         # counts of the very first step
@@ -535,6 +547,7 @@ def main():
                           "using two graphs around an eager all-reduce", file=sys.stderr, flush=True)
                 step = None
         if step is None:                                  # collectives stay outside the captured regions
+            overlap["early"] = False
             g_fb, g_opt = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
             with torch.cuda.graph(g_fb):
                 fwd_bwd()

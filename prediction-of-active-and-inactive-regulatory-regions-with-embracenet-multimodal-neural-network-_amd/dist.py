@@ -151,24 +151,29 @@ class BucketedFlatGrads:
     asynchronously (RCCL runs it on its own stream behind the work enqueued so far), `finish()` waits for it and reduces the
     second bucket.  Both are capturable into a step graph with the RCCL backend."""
 
-    def __init__(self, model):
+    def __init__(self, model, extra=0):
         early, late = [], []
         for name, p in model.named_parameters():
             if p.requires_grad:
                 (early if name.startswith(("embracenet.", "post.")) else late).append(p)
         self.early = FlatGrads(early) if early else None
-        self.late = FlatGrads(late) if late else None
+        self.late = FlatGrads(late, extra=extra) if (late or extra) else None   # `extra` slots ride in the LAST collective
+        self.extra = self.late.extra if self.late is not None else None
         self._work = None
+
+    @staticmethod
+    def _active():
+        return dist.is_initialized() and (world_size() > 1 or FORCE_COLLECTIVES)
 
     def buckets(self):
         return [b for b in (self.early, self.late) if b is not None]
 
     def allreduce_early(self):
-        if self.early is not None and world_size() > 1:
+        if self.early is not None and self._active():
             self._work = dist.all_reduce(self.early.flat, op=dist.ReduceOp.SUM, async_op=True)
 
     def finish(self):
-        if world_size() == 1:
+        if not self._active():
             return
         if self._work is not None:
             self._work.wait()
