@@ -262,7 +262,12 @@ int emb_convblock_needs_y(int B, int L, int cin_pad, int Cout, int k, int dtype)
  * per-slice partial sums into the caller's workspace and finish with a (deterministic, fixed-order) reduction launch.
  * After emb_reduce_defer(1) those reductions are only queued; emb_reduce_flush(stream) runs ALL queued ones in one launch.
  * Until the flush the parameter gradients are incomplete and every workspace handed to a queued call must stay untouched
- * (give each call site its own workspace).  Process-wide switch, default off (immediate). */
+ * (give each call site its own workspace).  Process-wide switch, default off (immediate).
+ * The multi-tensor optimizer entry points (emb_adam_step_multi / emb_rmsprop_step_multi / emb_nadam_step_multi) CONSUME queued
+ * jobs: a job whose outputs are gradient tensors of the launch is taken off the queue and its slices are summed inside the
+ * optimizer launch (fixed order: same result as the reduction launch, which then is not needed at all); the summed gradient is
+ * also stored to the gradient tensor.  Jobs that are not claimed stay queued for emb_reduce_flush.  Both entry points first
+ * launch a parked rider (emb_rider_flush), which may be the producer of a queued slab. */
 int emb_reduce_defer(int on);
 int emb_reduce_flush(emb_stream_t stream);
 
