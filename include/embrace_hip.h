@@ -9,8 +9,9 @@
  *
  * Conventions
  *  - plain pointers and sizes only; every pointer is DEVICE memory unless marked "host";
- *  - the caller owns every buffer; the library allocates nothing and keeps no state besides a
- *    thread-local error string;
+ *  - the caller owns every buffer; the library allocates no device memory.  Host-side state it keeps: the thread-local
+ *    error string, the queue of deferred slab reductions (emb_reduce_defer), the registry of packed conv-weight images
+ *    (emb_conv_pack_register) and at most one parked rider launch per thread (emb_rider_defer);
  *  - every call only ENQUEUES work on `stream` (a hipStream_t passed as void*), never synchronises,
  *    never reads device memory from the host -> safe under hipGraph stream capture;
  *  - return value: 0 on success, negative EMB_ERR_* otherwise (text via emb_last_error());
