@@ -51,6 +51,7 @@ CASES = [
     ("short37", 21, [(4, 16, 5)], 37),
     ("cfg5", 20, [(4, 64, 11), (64, 64, 11)]),            # 64 -> 64 channels: the streaming weight-gradient kernel with 128-byte dy rows
     ("short70", 33, [(4, 64, 15), (64, 64, 15), (64, 32, 3)], 70),   # L = 31 and 11: four / eleven sequences per 128-row tile
+    ("dual64", 12, [(4, 64, 15), (64, 64, 3), (64, 32, 5)]),          # 64 -> 64, k = 3: weight + input gradient in one launch (<4, 2>)
 ]
 
 
