@@ -19,7 +19,8 @@
 
 namespace emb {
 
-constexpr int kCtsWaves = 8, kCtsNT = 4, kCtsBT = kCtsWaves * 16 * kCtsNT;   // 512 output rows per tile
+constexpr int kCtsWaves = 8, kCtsNT = 4, kCtsBT = kCtsWaves * 16 * kCtsNT;   // 512 output rows per tile (NT = 4 row tiles per wave);
+                                                                             // NT = 2 (256 rows) when the 512-row image does not fit in LDS
 constexpr int kCtsMaxXI = 12;                                                 // activation LDS-DMA instructions per wave
 
 struct CtsArgs {
@@ -31,10 +32,10 @@ struct CtsArgs {
   int B, L, cin, KK, N, pad, SB, slot, tiles_m, tpb, nblk_m, taps;
 };
 
-template <int MT, int CPT, bool FWD>   // channel tiles per workgroup; k-steps per tap (cin = 32 * CPT)
+template <int MT, int CPT, bool FWD, int NT = kCtsNT>   // channel tiles per workgroup; k-steps per tap (cin = 32 * CPT); row tiles per wave
 __device__ __forceinline__ void conv_t_stream_body(const CtsArgs& a, const int block) {
   using T = __bf16;
-  constexpr int NT = kCtsNT, WAVES = kCtsWaves, BN = 16 * MT, CPL = 4 * MT;
+  constexpr int WAVES = kCtsWaves, BN = 16 * MT, CPL = 4 * MT;
   constexpr int RS = 4 * CPT, PS = RS + 2, PITCH = PS * 16;              // 16-byte slots per activation row: real, with pad; bytes
   // (two pad slots: ds_read_b128 is served in 16-lane groups on 64 banks; with a pitch of an odd number of slots seven of eight
   // slots of a group collide two-way -- SQ_LDS_BANK_CONFLICT 2.3 per LDS instruction cycle --, a pitch of 2 mod 4 slots is free)
@@ -197,15 +198,15 @@ __device__ __forceinline__ void conv_t_stream_body(const CtsArgs& a, const int b
   }
 }
 
-template <int MT, int CPT, bool FWD>
+template <int MT, int CPT, bool FWD, int NT = kCtsNT>
 __global__ __launch_bounds__(kCtsWaves * 64, 2) void conv_t_stream_kernel(const CtsArgs a) {
-  conv_t_stream_body<MT, CPT, FWD>(a, (int)blockIdx.x);
+  conv_t_stream_body<MT, CPT, FWD, NT>(a, (int)blockIdx.x);
 }
 
 // LDS bytes of the streaming kernel, 0 when the shape does not qualify
-template <int MT> static size_t conv_t_stream_lds(int B, int L, int cin, int KK, int N, int pad) {
-  if (cin % 32 != 0 || cin > 128 || cin == 96 || KK % cin != 0 || L > kCtsBT || L < 1) return 0;
-  const ConvTiling t = conv_tiling_bt(B, L, pad, kCtsBT);
+template <int MT> static size_t conv_t_stream_lds(int B, int L, int cin, int KK, int N, int pad, int BT = kCtsBT) {
+  if (cin % 32 != 0 || cin > 128 || cin == 96 || KK % cin != 0 || L > BT || L < 1) return 0;
+  const ConvTiling t = conv_tiling_bt(B, L, pad, BT);
   if (t.tiles_t != 1) return 0;
   const int PS = cin / 8 + 2, xrows = t.SB * t.slot + kXExtra, nxi = (xrows * PS + 63) / 64, nks = KK / 32;
   if (nxi > 8 * kCtsMaxXI) return 0;                                     // plan registers
@@ -214,7 +215,7 @@ template <int MT> static size_t conv_t_stream_lds(int B, int L, int cin, int KK,
   return lds <= 160 * 1024 ? lds : 0;
 }
 
-template <int MT, int CPT, bool FWD>
+template <int MT, int CPT, bool FWD, int NT>
 static int launch_conv_t_stream_cfg(const CtsArgs& a0, size_t lds, int tiles_n, hipStream_t s) {
   CtsArgs a = a0;
   const int target = 256;
@@ -223,31 +224,41 @@ static int launch_conv_t_stream_cfg(const CtsArgs& a0, size_t lds, int tiles_n, 
   a.nblk_m = cdiv(a.tiles_m, tpb);
   static bool attr = false;
   if (!attr) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_t_stream_kernel<MT, CPT, FWD>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_t_stream_kernel<MT, CPT, FWD, NT>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     attr = true;
   }
-  conv_t_stream_kernel<MT, CPT, FWD><<<a.nblk_m * tiles_n, kCtsWaves * 64, lds, s>>>(a);
+  conv_t_stream_kernel<MT, CPT, FWD, NT><<<a.nblk_m * tiles_n, kCtsWaves * 64, lds, s>>>(a);
   EMB_CHECK_LAUNCH();
   return a.nblk_m;
+}
+
+// returns the number of partial rows (> 0) when the streaming kernel ran, 0 when the shape does not qualify, < 0 on error
+template <int MT, bool FWD, int NT>
+static int launch_conv_t_stream_nt(const void* x, const void* w, const void* bias, void* out, void* partial, int B, int L, int cin, int KK, int N,
+                                   int pad, hipStream_t s) {
+  constexpr int BT = kCtsWaves * 16 * NT;
+  const size_t lds = conv_t_stream_lds<MT>(B, L, cin, KK, N, pad, BT);
+  if (lds == 0 || !aligned16(x) || !aligned16(w) || !aligned16(out)) return 0;
+  const ConvTiling t = conv_tiling_bt(B, L, pad, BT);
+  CtsArgs a{};
+  a.x = (const __bf16*)x; a.w = (const __bf16*)w; a.bias = (const float*)bias; a.out = (__bf16*)out; a.partial = (float*)partial;
+  a.B = B; a.L = L; a.cin = cin; a.KK = KK; a.N = N; a.pad = pad; a.SB = t.SB; a.slot = t.slot; a.tiles_m = t.tiles_m; a.taps = KK / cin;
+  const int tiles_n = cdiv(N, 16 * MT);
+  switch (cin / 32) {
+    case 1: return launch_conv_t_stream_cfg<MT, 1, FWD, NT>(a, lds, tiles_n, s);
+    case 2: return launch_conv_t_stream_cfg<MT, 2, FWD, NT>(a, lds, tiles_n, s);
+    case 4: return launch_conv_t_stream_cfg<MT, 4, FWD, NT>(a, lds, tiles_n, s);
+  }
+  return 0;
 }
 
 // returns the number of partial rows (> 0) when the streaming kernel ran, 0 when the shape does not qualify, < 0 on error
 template <int MT, bool FWD>
 static int launch_conv_t_stream(const void* x, const void* w, const void* bias, void* out, void* partial, int B, int L, int cin, int KK, int N,
                                 int pad, hipStream_t s) {
-  const size_t lds = conv_t_stream_lds<MT>(B, L, cin, KK, N, pad);
-  if (lds == 0 || !aligned16(x) || !aligned16(w) || !aligned16(out)) return 0;
-  const ConvTiling t = conv_tiling_bt(B, L, pad, kCtsBT);
-  CtsArgs a{};
-  a.x = (const __bf16*)x; a.w = (const __bf16*)w; a.bias = (const float*)bias; a.out = (__bf16*)out; a.partial = (float*)partial;
-  a.B = B; a.L = L; a.cin = cin; a.KK = KK; a.N = N; a.pad = pad; a.SB = t.SB; a.slot = t.slot; a.tiles_m = t.tiles_m; a.taps = KK / cin;
-  const int tiles_n = cdiv(N, 16 * MT);
-  switch (cin / 32) {
-    case 1: return launch_conv_t_stream_cfg<MT, 1, FWD>(a, lds, tiles_n, s);
-    case 2: return launch_conv_t_stream_cfg<MT, 2, FWD>(a, lds, tiles_n, s);
-    case 4: return launch_conv_t_stream_cfg<MT, 4, FWD>(a, lds, tiles_n, s);
-  }
-  return 0;
+  const int rc = launch_conv_t_stream_nt<MT, FWD, 4>(x, w, bias, out, partial, B, L, cin, KK, N, pad, s);
+  if (rc != 0) return rc;
+  return launch_conv_t_stream_nt<MT, FWD, 2>(x, w, bias, out, partial, B, L, cin, KK, N, pad, s);   // 256-row tiles: half the image
 }
 
 }  // namespace emb
