@@ -258,6 +258,11 @@ int emb_convblock_bwd(const void* dout, int dout_ncl, const uint8_t* argmax, con
                       void* workspace, int64_t workspace_bytes, int x_codes, int bn_phase, double* bn_sums, int B, int L,
                       int Cin, int cin_pad, int Cout, int k, int dtype, emb_stream_t stream);
 int emb_convblock_needs_y(int B, int L, int cin_pad, int Cout, int k, int dtype);
+/* elements (of P) the `stats` buffer of emb_convblock_fwd / emb_convblock_bwd must have: 4 * Cout, plus -- for the fused first
+ * block in bf16 -- the lag statistics of the input that the forward leaves there for the recompute-free backward
+ * (csrc/first_gram.h: the first block's convolution is linear in its weights, so the BatchNorm backward is assembled from
+ * A = g^T xview, the input's lag statistics and the weights instead of re-running the convolution twice). */
+int64_t emb_convblock_stats_elems(int B, int L, int cin_pad, int Cout, int k, int dtype);
 
 /* Slab reductions.  The weight-gradient kernels of emb_embrace_bwd / emb_linear_bwd / emb_mlp_bwd / emb_convblock_bwd write
  * per-slice partial sums into the caller's workspace and finish with a (deterministic, fixed-order) reduction launch.

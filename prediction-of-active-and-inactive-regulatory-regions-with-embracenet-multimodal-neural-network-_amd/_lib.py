@@ -65,6 +65,7 @@ SIGNATURES = {
     "emb_reduce_defer": [_i],
     "emb_reduce_flush": [_vp],
     "emb_convblock_needs_y": [_i, _i, _i, _i, _i, _i],
+    "emb_convblock_stats_elems": [_i, _i, _i, _i, _i, _i],
     "emb_cast": [_vp, _i, _vp, _i, _i64, _vp],
     "emb_counter_add": [_vp, _u64, _vp],
 }
@@ -96,6 +97,7 @@ def lib():
             fn.argtypes = argtypes
             fn.restype = {"emb_last_error": ctypes.c_char_p,
                           "emb_convblock_workspace_bytes": ctypes.c_int64,
+                          "emb_convblock_stats_elems": ctypes.c_int64,
                           "emb_mlp_workspace_bytes": ctypes.c_int64,
                           "emb_head_ce_workspace_bytes": ctypes.c_int64}.get(name, ctypes.c_int)
         if L.emb_abi_version() != 1:

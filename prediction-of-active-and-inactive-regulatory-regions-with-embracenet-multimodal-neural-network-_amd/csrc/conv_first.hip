@@ -23,6 +23,7 @@
 #include "conv_tiles.h"
 #include "rider.h"
 #include "bn_inline.h"
+#include "first_gram.h"
 #include "philox.h"
 
 namespace emb {
@@ -35,8 +36,17 @@ __device__ int g_first_sel;
 #define FIRST_T(i) do {} while (0)
 #endif
 
+// n / d for 0 <= n < 2^16, d >= 1 with rd = 1.0f / d: a handful of instructions instead of the ~35 of an integer division by a
+// runtime value (the row-offset tables below need dozens of these per thread)
+__device__ __forceinline__ int small_div(int n, int d, float rd) {
+  int q = (int)((float)n * rd);
+  q -= (q * d > n);
+  q += ((q + 1) * d <= n);
+  return q;
+}
+
 constexpr int kFBT = 256, kFXV = 2;            // rows per workgroup tile; activation vectors per thread (tile <= 512 rows)
-enum { F_STATS = 0, F_APPLY = 1, F_BSUMS = 2, F_BWGRAD = 3 };
+enum { F_STATS = 0, F_APPLY = 1, F_BSUMS = 2, F_BWGRAD = 3, F_BACC = 4 };   // F_BACC: A = g^T xview only (first_gram.h), no convolution
 
 struct FirstArgs {
   const void* x;            // x_codes == 0: [B][L][8] bf16 channels-last, zero-padded channels
@@ -61,6 +71,13 @@ struct FirstArgs {
   float drop_p, keep_scale;
   int ncl, training, layer_id;
   int B, L, Lp, KK, C, pad, SB, slot, tiles_m, tpb;
+  // Lag statistics of the INPUT (first_gram.h): F_STATS writes one partial row of kGramRow floats per workgroup to `gram_part`
+  // (nullptr: not wanted); F_APPLY's prologue sums the `gram_rows` partial rows column-wise (each workgroup a few columns) into
+  // `gram_tot`, which the recompute-free backward (first_bwd_finish_kernel) reads.
+  float* gram_part;
+  float* gram_tot;
+  __bf16* gram_edge;        // the edge image (first_gram.h): F_STATS writes it, F_APPLY's jobs read it
+  int gram_rows;
   BnFinFwd fin_f;           // F_APPLY: partial != nullptr -> the statistics are finalised in this launch's prologue (bn_inline.h)
   BnFinBwd fin_b;           // F_BWGRAD: likewise for coef / dgamma / dbeta
 };
@@ -76,6 +93,8 @@ __device__ __forceinline__ void first_body(const FirstArgs& a, const int bm) {
   using T = __bf16;
   typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
   constexpr int CPL = 4 * MT, GW = 16 * MT, BN = GW * CH, XS = 8, NW = 4 * CH, NTHR = 256 * CH;
+  constexpr bool BW = MODE == F_BWGRAD || MODE == F_BACC;   // passes that build a dense gradient tile and run the weight-gradient MFMAs
+  constexpr int NIW_G = 8 / NW;                         // column blocks of the lag-statistics MFMA per wave
   constexpr int ZP = BN + 8;                            // pitch of the row-major bf16 tile (BN+ReLU output / dz)
   extern __shared__ __attribute__((aligned(16))) char arena[];
   const int L = a.L, Lp = a.Lp, C = a.C, SB = a.SB, slot = a.slot, KK = a.KK;
@@ -86,10 +105,11 @@ __device__ __forceinline__ void first_body(const FirstArgs& a, const int bm) {
   T* zt = xs + ((xrows * XS + 7) & ~7);                                // F_APPLY: BN/ReLU output, F_BWGRAD: dz; [256][ZP] bf16
   constexpr int XP = BN + 4;                                           // F_BSUMS: fp32 xhat tile [256][XP] in the zt region
   float* xt = reinterpret_cast<float*>(zt);
-  T* dp = zt + ((MODE == F_APPLY || MODE == F_BWGRAD) ? kFBT * ZP : (MODE == F_BSUMS ? 2 * kFBT * XP : 0));   // backward: pooled gradient [SB*Lp][DPP]
+  constexpr int FP = BN + 4;                                           // F_BACC: fp32 scatter tile [256][FP] behind the bf16 tile
+  float* ft = reinterpret_cast<float*>(zt + kFBT * ZP);
+  T* dp = zt + ((MODE == F_APPLY || BW) ? kFBT * ZP : (MODE == F_BSUMS ? 2 * kFBT * XP : 0)) + (MODE == F_BACC ? 2 * kFBT * FP : 0);   // backward: pooled gradient [SB*Lp][DPP]
   uint8_t* am = reinterpret_cast<uint8_t*>(dp + (MODE >= F_BSUMS ? SB * Lp * DPP : 0));   // backward: argmax bytes [SB*Lp][AMP]
-  int* rowmap = reinterpret_cast<int*>(am + (MODE >= F_BSUMS ? ((SB * Lp * AMP + 15) & ~15) : 0));   // F_BWGRAD: [256]
-  float* red = reinterpret_cast<float*>(rowmap + (MODE == F_BWGRAD ? kFBT : 0));                      // [4][2][BN]
+  float* red = reinterpret_cast<float*>(am + (MODE >= F_BSUMS ? ((SB * Lp * AMP + 15) & ~15) : 0));   // [4][2][BN]
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, g = lane >> 4, r16 = lane & 15;
   const int grp = wave % CH, rq = wave / CH, gcol = grp * GW;   // channel group, row quarter, first channel of the group
   const int tm_begin = bm * a.tpb, tm_end = min(a.tiles_m, tm_begin + a.tpb);
@@ -172,9 +192,18 @@ __device__ __forceinline__ void first_body(const FirstArgs& a, const int bm) {
   if (MODE == F_APPLY || MODE == F_BWGRAD) {
     double* fin_scratch = reinterpret_cast<double*>(arena);                  // the arena is not in use before the first tile
     float* fin_out = reinterpret_cast<float*>(fin_scratch + NTHR * 4 + 2 * BN);   // [4][BN] floats
+    GramPre gpre;
+    gpre.have = false;
+    if (MODE == F_APPLY && a.gram_tot != nullptr && bm < kGramJobs) gpre = gram_job_preload<NTHR>(bm, a.gram_edge, a.B, L);   // (loads in flight below)
     if (MODE == F_APPLY && a.fin_f.partial != nullptr) {
       bn_fin_fwd<NTHR>(a.fin_f, C, fin_scratch, fin_out, bm == 0);
       st_src = fin_out;
+    }
+    if (MODE == F_APPLY && a.gram_tot != nullptr) {   // totals of the lag statistics, one job per workgroup (first_gram.h)
+      for (int job = bm; job < kGramJobs; job += (int)gridDim.x) {
+        gram_job<NTHR>(job, gpre, a.gram_edge, a.B, L, a.gram_part, a.gram_rows, a.gram_tot, reinterpret_cast<float*>(fin_scratch));
+        gpre.have = false;
+      }
     }
     if (MODE == F_BWGRAD && a.fin_b.partial != nullptr) {
       bn_fin_bwd<NTHR>(a.fin_b, C, fin_scratch, fin_out, bm == 0);
@@ -202,6 +231,7 @@ __device__ __forceinline__ void first_body(const FirstArgs& a, const int bm) {
       } else if (MODE == F_BSUMS) {
         k0[mt][r] = a.stats[ch] - bias;
         k1[mt][r] = a.stats[C + ch];
+      } else if (MODE == F_BACC) {
       } else {
         const float mean = a.stats[ch], inv = a.stats[C + ch], sc = a.stats[2 * C + ch];
         const float bc = a.training ? -sc * cf_src[C + ch] * inv : 0.0f;
@@ -227,14 +257,25 @@ __device__ __forceinline__ void first_body(const FirstArgs& a, const int bm) {
     row_sq[nt] = sq;
     row_t[nt] = row < SB * L ? rr - sq * L : -1;
   }
-  if (MODE == F_BWGRAD && threadIdx.x < kFBT) {
-    const int row = threadIdx.x, rr = min(row, SB * L - 1), sq = rr / L;
-    rowmap[row] = sq * slot + (rr - sq * L);
-  }
+  // LDS element offset of tile row `row` (k-step rows of the weight-gradient / lag-statistics MFMAs): computed in the loops, cheap
+  // with small_div -- a table in registers costs occupancy, a table in LDS serialises map read -> fragment read -> MFMA
+  const float rL = 1.0f / (float)L;
+  auto row_off = [&](int row) {
+    const int rr = min(row, SB * L - 1), sq = small_div(rr, L, rL);
+    return (sq * slot + (rr - sq * L)) * XS;
+  };
+  // lag statistics (first_gram.h): MFMA accumulator of G0 = x~[r - pad]^T . xview (this wave's column blocks), accumulated over the
+  // workgroup's tiles
+  typename Mm::AccV accg[NIW_G];
+#pragma unroll
+  for (int ni = 0; ni < NIW_G; ++ni)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) accg[ni][r] = 0;
+  const bool gram = MODE == F_STATS && a.gram_part != nullptr;
   // weight-gradient accumulators: all MIW channel tiles x this wave's n-blocks (16 columns of k*8) nb = ni*NW + wave
   constexpr int MIW = MT * CH, NIW = 8 / NW;
-  typename Mm::AccV accw[MODE == F_BWGRAD ? MIW : 1][NIW];
-  if (MODE == F_BWGRAD) {
+  typename Mm::AccV accw[BW ? MIW : 1][NIW];
+  if (BW) {
 #pragma unroll
     for (int mi = 0; mi < MIW; ++mi)
 #pragma unroll
@@ -250,11 +291,32 @@ __device__ __forceinline__ void first_body(const FirstArgs& a, const int bm) {
   if (MODE != F_STATS) {
 #pragma unroll
     for (int i = 0; i < NIT; ++i) {
-      const int it = threadIdx.x + i * NTHR, c0 = (it % CV) * 8, sp = it / CV, sq = sp / Lp, p = sp - sq * Lp;
+      const int it = threadIdx.x + i * NTHR, c0 = (it % CV) * 8;
+      int sp = it / CV, sq = sp / Lp, p = sp - sq * Lp;
+      if (MODE == F_BACC) {
+        // the scatter below works in five rounds by p % 5: the windows are dealt to the threads SORTED by that phase (then sequence,
+        // then p), so that the 64 / CV windows of a wave share a phase and a wave runs the scatter code once, not once per round
+        int w = sp, ph = 0;
+        for (; ph < 5; ++ph) {
+          const int n = SB * ((Lp - ph + 4) / 5);
+          if (w < n) break;
+          w -= n;
+        }
+        const int nq = ph < 5 ? (Lp - ph + 4) / 5 : 1;
+        sq = ph < 5 ? w / nq : SB;
+        p = ph < 5 ? 5 * (w - sq * nq) + ph : 0;
+        sp = sq * Lp + p;
+      }
       it_row[i] = MODE == F_APPLY ? ((sq * L + 2 * p) | (c0 << 16)) : (sp | (c0 << 16));   // backward: LDS row sp of dp / am
       it_pc[i] = sq < SB ? (p | (sq << 8)) : -1;
     }
   }
+  // F_BACC: the pooled gradient is SCATTERED into a dense tile: window p of a sequence gives its gradient to row 2p + argmax.
+  // Windows p and p + 5 share no row (10 rows, stride 2), so the items with p % 5 == ph touch distinct (row, channel) cells: five
+  // rounds of plain read-modify-write, no atomics, a fixed order of additions.
+  int it_ph[NIT];
+#pragma unroll
+  for (int i = 0; i < NIT; ++i) it_ph[i] = MODE == F_BACC && it_pc[i] >= 0 ? (it_pc[i] & 0xFF) % 5 : -1;
   // backward: the tile's pooled gradient and argmax bytes travel global -> registers -> LDS like the activations
   bf16x8 gv[MODE >= F_BSUMS ? NIT : 1];
   uint64_t av[MODE >= F_BSUMS ? NIT : 1];
@@ -267,7 +329,8 @@ __device__ __forceinline__ void first_body(const FirstArgs& a, const int bm) {
       gv[i] = __builtin_bit_cast(bf16x8, make_uint4(0u, 0u, 0u, 0u));   // (whole-vector write: element writes would push the array to scratch)
       av[i] = 0x8080808080808080ull;                   // "dropped": matches no window offset
       if (it_pc[i] >= 0 && (it_pc[i] >> 8) < nseq) {
-        const long off = (long)(threadIdx.x + i * NTHR) * 8;     // items are laid out exactly as [sq][p][c]
+        const long off = MODE == F_BACC ? (long)(it_row[i] & 0xFFFF) * C + (it_row[i] >> 16)   // (phase-sorted items)
+                                        : (long)(threadIdx.x + i * NTHR) * 8;                   // items are laid out exactly as [sq][p][c]
         gv[i] = *reinterpret_cast<const bf16x8*>(gsrc + off);
         av[i] = *reinterpret_cast<const uint64_t*>(asrc + off);
       }
@@ -305,7 +368,7 @@ __device__ __forceinline__ void first_body(const FirstArgs& a, const int bm) {
       if (!a.ncl) {
 #pragma unroll
         for (int i = 0; i < NIT; ++i)
-          if (MODE == F_BWGRAD && it_pc[i] >= 0) {   // F_BSUMS consumes the registers directly (window-space sums)
+          if (MODE == F_BWGRAD && it_pc[i] >= 0) {   // F_BSUMS / F_BACC consume the registers directly
             const int sp = it_row[i] & 0xFFFF, c0 = it_row[i] >> 16;
             *reinterpret_cast<bf16x8*>(dp + sp * DPP + c0) = gv[i];
             *reinterpret_cast<uint64_t*>(am + sp * AMP + c0) = av[i];
@@ -319,17 +382,83 @@ __device__ __forceinline__ void first_body(const FirstArgs& a, const int bm) {
         }
       }
     }
+    if (MODE == F_BACC) {                                // zero the scatter tile: 256 * FP floats, 16 bytes per store
+      const float4 z4 = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+      for (int i = threadIdx.x; i < kFBT * FP / 4; i += NTHR) reinterpret_cast<float4*>(ft)[i] = z4;
+    }
     __syncthreads();
     FIRST_T(2 + (tm - tm_begin) * 8 + 2);
-    if (tm + 1 < tm_end) {
+    if (MODE == F_BACC) {
+      // this tile's items move to a second register set and the next tile's loads start now: a whole tile of time to land
+      bf16x8 gcur[NIT];
+      uint64_t acur[NIT];
+#pragma unroll
+      for (int i = 0; i < NIT; ++i) { gcur[i] = gv[i]; acur[i] = av[i]; }
+      if (tm + 1 < tm_end) {
+        issue_x(tm + 1);
+        if (!a.ncl) issue_g(tm + 1);
+      }
+      FIRST_T(2 + (tm - tm_begin) * 8 + 6);
+#pragma unroll 1
+      for (int ph = 0; ph < 5; ++ph) {
+#pragma unroll
+        for (int i = 0; i < NIT; ++i)
+          if (it_ph[i] == ph && (it_pc[i] >> 8) < nseq) {
+            const int sp = it_row[i] & 0xFFFF, c0 = it_row[i] >> 16, sq = it_pc[i] >> 8, p = it_pc[i] & 0xFF;
+            bf16x8 gq;
+            uint64_t aq;
+            if (!a.ncl) {
+              gq = gcur[i];
+              aq = acur[i];
+            } else {
+              gq = *reinterpret_cast<const bf16x8*>(dp + sp * DPP + c0);
+              aq = *reinterpret_cast<const uint64_t*>(am + sp * AMP + c0);
+            }
+            // the eight channels are eight different columns: all reads first, then the writes (one LDS round trip, not eight).
+            // Channels without a gradient (bit 6 / 7 of the code: ReLU zero / dropped) add into the row's pad columns, which
+            // nobody reads: no branches
+            float* cell = ft + (sq * L + 2 * p) * FP + c0;
+            float cur[8];
+            int off[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+              const int code = (int)((aq >> (8 * e)) & 0xFF);
+              off[e] = code < 0x40 ? code * FP + e : BN - c0 + (e & 3);
+              cur[e] = cell[off[e]];
+            }
+#pragma unroll
+            for (int e = 0; e < 8; ++e) cell[off[e]] = cur[e] + (float)gq[e];
+          }
+        __syncthreads();
+      }
+      FIRST_T(2 + (tm - tm_begin) * 8 + 5);
+      // fp32 -> the bf16 A-operand tile: thread (row, 32-channel half)
+      for (int i = threadIdx.x; i < kFBT * (BN / 8); i += NTHR) {
+        const int row = i / (BN / 8), c8 = (i - row * (BN / 8)) * 8;
+        const float4 v0 = *reinterpret_cast<const float4*>(ft + row * FP + c8), v1 = *reinterpret_cast<const float4*>(ft + row * FP + c8 + 4);
+        bf16x8 o;
+        o[0] = (T)(v0.x * a.keep_scale); o[1] = (T)(v0.y * a.keep_scale); o[2] = (T)(v0.z * a.keep_scale); o[3] = (T)(v0.w * a.keep_scale);
+        o[4] = (T)(v1.x * a.keep_scale); o[5] = (T)(v1.y * a.keep_scale); o[6] = (T)(v1.z * a.keep_scale); o[7] = (T)(v1.w * a.keep_scale);
+        *reinterpret_cast<bf16x8*>(zt + row * ZP + c8) = o;
+      }
+    }
+    if (MODE != F_BACC && tm + 1 < tm_end) {
       issue_x(tm + 1);
-      if (MODE == F_BWGRAD) {
+      if (BW) {
         if (!a.ncl) issue_g(tm + 1);
       }
     }
+    if (MODE == F_STATS) {   // (after the next tile's loads are in flight: this phase hides their latency)
+      if (gram) {
+        gram_edge_store(xs, a.gram_edge, a.B, L, slot, a.pad, b0, nseq);
+        if (SB == 1) gram_tile<NW, NIW_G, 4>(xs, [&](int row) { return min(row, L - 1) * XS; }, accg, L, SB, slot, lane, wave);   // one sequence per tile: no division
+        else gram_tile<NW, NIW_G, 2>(xs, row_off, accg, L, SB, slot, lane, wave);
+      }
+    }
+    FIRST_T(2 + (tm - tm_begin) * 8 + 1);
 
 #pragma unroll 1
-    for (int h = 0; h < 2; ++h) {                      // two row tiles at a time (accumulator registers); a real loop: the
+    for (int h = 0; h < (MODE == F_BACC ? 0 : 2); ++h) {   // two row tiles at a time (accumulator registers); a real loop: the
                                                        // unrolled form interleaves the halves and doubles the live registers
       const int xrow_h[2] = {h ? xrow[2] : xrow[0], h ? xrow[3] : xrow[1]};
       const int sq_h[2] = {h ? row_sq[2] : row_sq[0], h ? row_sq[3] : row_sq[1]};
@@ -342,7 +471,7 @@ __device__ __forceinline__ void first_body(const FirstArgs& a, const int bm) {
 #pragma unroll
           for (int r = 0; r < 4; ++r) acc[mt][j][r] = 0;
 #pragma unroll
-      for (int ks = 0; ks < 4; ++ks) {
+      for (int ks = 0; ks < (MODE == F_BACC ? 0 : 4); ++ks) {   // (F_BACC needs no convolution)
         if (ks < nks) {
           bf16x8 bf[2];
 #pragma unroll
@@ -437,7 +566,7 @@ __device__ __forceinline__ void first_body(const FirstArgs& a, const int bm) {
             for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
               for (int r = 0; r < 4; ++r) {
-                const float dz = k0[mt][r] * dy[mt * 4 + r] + k1[mt][r] * acc[mt][j][r] + k2[mt][r];
+                const float dz = MODE == F_BACC ? dy[mt * 4 + r] : k0[mt][r] * dy[mt * 4 + r] + k1[mt][r] * acc[mt][j][r] + k2[mt][r];
                 ov[mt * 4 + r] = (T)(rv ? dz : 0.0f);
               }
             T* dst = zt + row * ZP + gcol + g * CPL;
@@ -554,7 +683,7 @@ __device__ __forceinline__ void first_body(const FirstArgs& a, const int bm) {
     }
 
     FIRST_T(2 + (tm - tm_begin) * 8 + 4);
-    if (MODE == F_BWGRAD) {
+    if (BW) {
       __syncthreads();
       // dW[o][n] += sum_r dz[r][o] * xview[r][n]:  A = dz^T (tr16 reads of the row-major tile), B = x view, K = 256 rows.
       // column KK of the B operand is forced to ones: slab column KK = sum_r dz = bias gradient
@@ -571,7 +700,7 @@ __device__ __forceinline__ void first_body(const FirstArgs& a, const int bm) {
           u.s.hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(a0 + 4 * ZP));
           af[mi] = u.v;
         }
-        const int x0 = rowmap[ra] * XS, x1 = rowmap[ra + 4] * XS;
+        const int x0 = row_off(ra), x1 = row_off(ra + 4);
 #pragma unroll
         for (int ni = 0; ni < NIW; ++ni) {
           const int nb = ni * NW + wave, xoff = nb * 16 + 4 * p4;   // column n = tap*8 + ci = LDS offset (pitch 8)
@@ -613,6 +742,10 @@ __device__ __forceinline__ void first_body(const FirstArgs& a, const int bm) {
       if (c < C) a.partial[((long)bm * 2 + which) * C + c] = t;
     }
   }
+  if (MODE == F_STATS) {
+    if (gram) gram_store<NW, NIW_G>(a.gram_part + (long)bm * kGramPart, accg, lane, wave);
+  }
+  FIRST_T(42);
   if (MODE == F_STATS) {   // one partial row per workgroup
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt)
@@ -632,7 +765,7 @@ __device__ __forceinline__ void first_body(const FirstArgs& a, const int bm) {
             ((red[(0 * 2 + which) * BN + c] + red[(1 * 2 + which) * BN + c]) + red[(2 * 2 + which) * BN + c]) + red[(3 * 2 + which) * BN + c];
     }
   }
-  if (MODE == F_BWGRAD) {
+  if (BW) {
     float* dst = a.slab + (long)bm * C * (KK + 1);
 #pragma unroll
     for (int mi = 0; mi < MIW; ++mi)
@@ -655,7 +788,7 @@ __global__ __launch_bounds__(256 * CH) void first_kernel(const FirstArgs a) {
 // the statistics pass carrying the forward of the epigenomic MLP stack as its first `nr` workgroups (rider.h): one wave of each
 // runs 16 rows of the stack, the pass's own workgroups follow
 template <int MT, int CH>
-__global__ __launch_bounds__(256 * CH) void first_stats_rider_kernel(const FirstArgs a, const MlpArgs<__bf16> fa, const MmFwdLayout fl, const int nr) {
+__global__ __launch_bounds__(256 * CH, 3) void first_stats_rider_kernel(const FirstArgs a, const MlpArgs<__bf16> fa, const MmFwdLayout fl, const int nr) {
   if ((int)blockIdx.x < nr) {
     extern __shared__ __attribute__((aligned(16))) char rider_arena[];
     if (threadIdx.x < 64) mlp_fwd_mfma_body(fa, fl, (int)blockIdx.x, rider_arena);
@@ -698,10 +831,10 @@ static bool first_geom(int B, int L, int cin_pad, int Cout, int k, FirstGeom* gm
 static size_t first_lds(int mode, const FirstGeom& gm, int Lp, int C) {
   const int BN = C, ZP = BN + 8, DPP = BN + 8, AMP = BN + 8;
   size_t bytes = (((size_t)gm.xrows * 8 + 7) & ~(size_t)7) * 2;
-  if (mode == F_APPLY || mode == F_BWGRAD) bytes += (size_t)kFBT * ZP * 2;
+  if (mode == F_APPLY || mode == F_BWGRAD || mode == F_BACC) bytes += (size_t)kFBT * ZP * 2;
+  if (mode == F_BACC) bytes += (size_t)kFBT * (BN + 4) * 4;   // fp32 scatter tile
   if (mode == F_BSUMS) bytes += (size_t)kFBT * (BN + 4) * 4;
   if (mode >= F_BSUMS) bytes += (size_t)gm.SB * Lp * DPP * 2 + (((size_t)gm.SB * Lp * AMP + 15) & ~(size_t)15);
-  if (mode == F_BWGRAD) bytes += kFBT * sizeof(int);
   bytes += (size_t)4 * 2 * BN * sizeof(float);
   return (bytes + 15) & ~(size_t)15;
 }
@@ -763,19 +896,21 @@ static void first_fill(FirstArgs& a, const FirstGeom& gm, int B, int L, int Cout
   a.SB = gm.SB; a.slot = gm.slot; a.tiles_m = gm.tiles_m; a.tpb = gm.tpb;
 }
 
-int conv_first_stats(const void* x, int x_codes, void* nlc_out, const void* w, const void* bias, void* partial, int* rows, int B, int L, int Cout,
-                     int k, hipStream_t s) {
+int conv_first_stats(const void* x, int x_codes, void* nlc_out, const void* w, const void* bias, void* partial, int* rows, float* gram_part,
+                     int B, int L, int Cout, int k, hipStream_t s) {
   FirstGeom gm;
   if (!first_geom(B, L, 8, Cout, k, &gm)) return 1;
   FirstArgs a{};
   first_fill(a, gm, B, L, Cout, k);
   a.x = x; a.x_codes = x_codes; a.nlc_out = (__bf16*)nlc_out; a.w = (const __bf16*)w; a.bias = (const float*)bias; a.partial = (float*)partial;
+  a.gram_part = gram_part;
+  a.gram_edge = gram_part ? reinterpret_cast<__bf16*>(gram_part + (size_t)gm.nblk * kGramPart) : nullptr;
   *rows = gm.nblk;
   return first_launch<F_STATS>(a, gm, s);
 }
 
 int conv_first_apply(const void* x, int x_codes, const void* w, const void* bias, const void* stats, const BnFinFwd* fin, void* out,
-                     uint8_t* argmax, int out_ncl,
+                     uint8_t* argmax, int out_ncl, const float* gram_part, float* gram_tot,
                      float drop_p, uint64_t seed, uint64_t step_val, const uint64_t* step_dev, int64_t row0, int layer_id, int B, int L,
                      int Cout, int k, hipStream_t s) {
   FirstGeom gm;
@@ -786,6 +921,8 @@ int conv_first_apply(const void* x, int x_codes, const void* w, const void* bias
   a.out = (__bf16*)out; a.argmax = argmax; a.ncl = out_ncl; a.drop_p = drop_p; a.seed = seed; a.step_val = step_val;
   a.step_dev = step_dev; a.grow0 = row0; a.layer_id = layer_id;
   if (fin != nullptr) a.fin_f = *fin;
+  a.gram_part = const_cast<float*>(gram_part); a.gram_tot = gram_tot; a.gram_rows = gm.nblk;
+  a.gram_edge = gram_part ? reinterpret_cast<__bf16*>(const_cast<float*>(gram_part) + (size_t)gm.nblk * kGramPart) : nullptr;
   return first_launch<F_APPLY>(a, gm, s);
 }
 
@@ -817,6 +954,38 @@ int conv_first_bwd_wgrad(const void* dout, int dout_ncl, const uint8_t* argmax, 
   if (fin != nullptr) a.fin_b = *fin;
   *slices = gm.nblk;
   return first_launch<F_BWGRAD>(a, gm, s);
+}
+
+// recompute-free backward (first_gram.h): one pass A = g^T xview into per-workgroup slabs ...
+int conv_first_bwd_acc(const void* dout, int dout_ncl, const uint8_t* argmax, const void* x, int x_codes, float keep_scale, void* slab, int* slices, int B, int L,
+                       int Cout, int k, hipStream_t s) {
+  FirstGeom gm;
+  if (!first_geom(B, L, 8, Cout, k, &gm)) return 1;
+  FirstArgs a{};
+  first_fill(a, gm, B, L, Cout, k);
+  a.x = x; a.x_codes = x_codes; a.dout = (const __bf16*)dout; a.ncl = dout_ncl; a.argmax = const_cast<uint8_t*>(argmax); a.keep_scale = keep_scale;
+  a.training = 1; a.slab = (float*)slab;
+  *slices = gm.nblk;
+  return first_launch<F_BACC>(a, gm, s);
+}
+
+// ... and the per-channel finish: slab sums, lag statistics, weights -> dW (torch layout), dbias, dgamma, dbeta
+int conv_first_bwd_finish(const void* slab, int slices, const float* gram_tot, const void* w, const void* bias, const void* stats, void* dW,
+                          void* dbias, void* dgamma, void* dbeta, int training, int B, int L, int Cin, int Cout, int k, hipStream_t s) {
+  FirstFinArgs f{};
+  f.slab = (const float*)slab; f.gram = gram_tot; f.w = (const __bf16*)w; f.bias = (const float*)bias; f.stats = (const float*)stats;
+  f.dW = (float*)dW; f.dbias = (float*)dbias; f.dgamma = (float*)dgamma; f.dbeta = (float*)dbeta;
+  f.S = slices; f.C = Cout; f.k = k; f.Cin = Cin; f.pad = (k - 1) / 2; f.training = training; f.count = (double)B * L;
+  first_bwd_finish_kernel<<<Cout, 1024, 0, s>>>(f);
+  EMB_CHECK_LAUNCH();
+  return EMB_OK;
+}
+
+int conv_first_gram_floats() { return kGramRow; }
+size_t conv_first_gram_part_bytes(int B, int L, int cin_pad, int Cout, int k) {   // partial G0 rows, then the edge image
+  FirstGeom gm;
+  if (!first_geom(B, L, cin_pad, Cout, k, &gm)) return 0;
+  return (size_t)gm.nblk * kGramPart * sizeof(float) + (size_t)kGramEdgeRows * B * sizeof(__bf16);
 }
 
 }  // namespace emb

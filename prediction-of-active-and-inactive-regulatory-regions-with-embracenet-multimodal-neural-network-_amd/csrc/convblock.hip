@@ -629,7 +629,7 @@ __global__ void ncl_to_nlc_kernel(const S* __restrict__ x, T* __restrict__ out, 
 
 // ------------------------------------------------------------------------------- host plumbing
 struct ConvWs {
-  size_t stat_partial, bwd_partial, coef, slab, total;
+  size_t stat_partial, gram, bwd_partial, coef, slab, total;
   int tiles_m, nblk_bwd, rows_per_block, S, kper;
 };
 
@@ -663,9 +663,21 @@ template <typename T> static ConvWs conv_workspace(int B, int L, int cin_pad, in
   w.bwd_partial = al((size_t)w.nblk_bwd * 2 * Cout * sizeof(P));
   w.coef = al((size_t)2 * Cout * sizeof(P));
   w.slab = al((size_t)S * Cout * (KK + 1) * sizeof(P));
-  const size_t fwd = w.stat_partial, bwd = w.bwd_partial + w.coef + w.slab;
+  // fused first block in bf16: per-workgroup partial lag statistics of the input (first_gram.h), after the statistics partials
+  w.gram = (sizeof(T) == 2 && conv_first_supported(dtype_code<T>(), B, L, cin_pad, Cout, k))
+               ? al(conv_first_gram_part_bytes(B, L, cin_pad, Cout, k)) : 0;
+  const size_t fwd = w.stat_partial + w.gram, bwd = w.bwd_partial + w.coef + w.slab;
   w.total = fwd > bwd ? fwd : bwd;
   return w;
+}
+
+// the recompute-free backward of the fused first block (first_gram.h) needs the forward to leave the lag statistics behind `stats`
+static bool first_linear_enabled() {
+  static const bool on = [] { const char* e = getenv("EMB_FIRST_LINEAR"); return !(e && e[0] == '0'); }();
+  return on;
+}
+template <typename T> static bool first_linear(int training, int bn_phase) {
+  return sizeof(T) == 2 && first_linear_enabled() && training && bn_phase == 0;
 }
 
 template <typename T>
@@ -690,7 +702,8 @@ static int convblock_fwd(const void* x, const void* wpack, const void* bias, con
                   "emb_convblock_fwd: y may only be NULL when emb_convblock_needs_y() returns 0");
     int rows = 0;
     if (training && bn_phase != 2) {
-      const int rc0 = conv_first_stats(x, x_codes, x_codes == 2 ? y : nullptr, wpack, bias, ws, &rows, B, L, Cout, k, s);
+      const int rc0 = conv_first_stats(x, x_codes, x_codes == 2 ? y : nullptr, wpack, bias, ws, &rows,
+                                       first_linear<T>(training, bn_phase) ? (float*)((char*)ws + w.stat_partial) : nullptr, B, L, Cout, k, s);
       if (rc0 != EMB_OK) return rc0 == 1 ? EMB_ERR_ARG : rc0;
     }
     if (x_codes == 2) {
@@ -721,7 +734,9 @@ static int convblock_fwd(const void* x, const void* wpack, const void* bias, con
       bn_finalize_kernel<P, P><<<Cout, 256, 0, s>>>((const P*)ws, rows, Cout, (double)R, nullptr, (const P*)gamma, (const P*)beta,
                                                    (P*)rmean, (P*)rvar, training, momentum, eps, (P*)stats, (long long*)nbt);
     EMB_CHECK_LAUNCH();
-    const int rc1 = conv_first_apply(x_img, x_codes, wpack, bias, stats, inl ? &fin : nullptr, out, argmax, out_ncl, drop_p, seed, step_val, step_dev,
+    const bool lin = first_linear<T>(training, bn_phase);   // lag statistics totals: behind the four BatchNorm vectors (emb_convblock_stats_elems)
+    const int rc1 = conv_first_apply(x_img, x_codes, wpack, bias, stats, inl ? &fin : nullptr, out, argmax, out_ncl,
+                                     lin ? (const float*)((char*)ws + w.stat_partial) : nullptr, lin ? (float*)stats + 4 * Cout : nullptr, drop_p, seed, step_val, step_dev,
                                      row0, layer_id, B, L, Cout, k, s);
     return rc1 == 1 ? EMB_ERR_ARG : rc1;
   }
@@ -797,6 +812,11 @@ static int convblock_bwd(const void* dout, int dout_ncl, const uint8_t* argmax, 
     EMB_CHECK_ARG((size_t)nb * 2 * Cout * sizeof(P) <= w.bwd_partial && (size_t)nb * Cout * (KK + 1) * sizeof(P) <= w.slab,
                   "emb_convblock_bwd: workspace layout too small for the fused first block");
     int rows = 0, S = 0, rc = EMB_OK;
+    if (first_linear<T>(training, bn_phase)) {   // one pass A = g^T xview + a per-channel finish: no convolution, no sums pass (first_gram.h)
+      rc = conv_first_bwd_acc(dout, dout_ncl, argmax, x, x_codes, keep_scale, slab, &S, B, L, Cout, k, s);
+      if (rc != EMB_OK) return rc == 1 ? EMB_ERR_ARG : rc;
+      return conv_first_bwd_finish(slab, S, (const float*)stats + 4 * Cout, wpack, bias, stats, dW, dbias, dgamma, dbeta, training, B, L, Cin, Cout, k, s);
+    }
     static const bool inline_fin = [] { const char* e = getenv("EMB_BN_INLINE"); return !(e && e[0] == '0'); }();
     BnFinBwd fin{};
     bool inl = false;
@@ -1016,6 +1036,10 @@ extern "C" int emb_convblock_fwd(const void* x, const void* wpack, const void* b
   }
   set_error("emb_convblock_fwd: unsupported dtype %d", dtype);
   return EMB_ERR_DTYPE;
+}
+
+extern "C" int64_t emb_convblock_stats_elems(int B, int L, int cin_pad, int Cout, int k, int dtype) {
+  return 4 * (int64_t)Cout + ((dtype == EMB_BF16 && conv_first_supported(dtype, B, L, cin_pad, Cout, k)) ? conv_first_gram_floats() : 0);
 }
 
 extern "C" int emb_convblock_needs_y(int B, int L, int cin_pad, int Cout, int k, int dtype) {

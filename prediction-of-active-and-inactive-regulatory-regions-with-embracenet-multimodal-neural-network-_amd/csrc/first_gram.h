@@ -1,0 +1,346 @@
+// Lag statistics of the first conv block's INPUT and the recompute-free backward built on them.
+//
+// The first block is Conv1d(4 -> C, k) -> BatchNorm1d -> ReLU -> MaxPool (CNN_pre.py:37-44) on a few-channel input x.  Its
+// convolution z[r][c] = sum_m W[c][m] xv[r][m] + b[c] (xv = the zero-padded k*cin view of x) is LINEAR in W, so every sum the
+// BatchNorm backward needs can be written with three small objects instead of re-running the convolution:
+//   A[c][m]  = sum_r g[r][c] xv[r][m]        (g = dL/dy after pool / ReLU backward; one pass over the pooled gradient: F_BACC)
+//   M[m'][m] = sum_r xv[r][m'] xv[r][m]      (depends on the input only)
+//   sx[m]    = sum_r xv[r][m]
+// with  sum g z = sum_m W A + b sum g,  sum z xv = W M + b sx,  xhat = (z - mean) inv:
+//   dgamma = inv (sum g z - mean sum g),  dbeta = sum g,  m1 = dbeta / R,  m2 = dgamma / R,
+//   dW[c][m] = scale_c (A - m1 sx - m2 inv (W M + (b - mean) sx))[c][m],   db = 0.
+// M is block-Toeplitz up to the zero padding at the sequence ends: with P(u, d) = sum_b x_b[u] (x) x_b[u + d] (4 x 4, zero
+// past the sequence),  M(t1, t2) = Tot[d] - Head[max(0, t1 - pad)][d] - Tail[max(0, pad - t1)][d]  for d = t2 - t1 >= 0
+// (transposed for d < 0), Tot[d] = sum_u P(u, d), Head[j] = sum_{u < j} P(u, .), Tail[j] = sum_{v < j} P(L - 1 - v, .).
+// The statistics pass (F_STATS) already has every input tile in LDS: it adds
+//   G0[ci][(tap, c2)] = sum_r x~[r - pad][ci] x~[r - pad + tap][c2] = Tot[tap] - Tail[pad][tap]      one MFMA per wave and k-step
+// and writes it as one partial row per workgroup.  The apply pass's prologue (gram_job) sums those rows column-wise and computes
+// the edge products P(u, d), P(L - 1 - u, d) for u < 7 straight from x (they touch 21 positions at either end of a sequence),
+// one job per workgroup, so the totals are in global memory when the backward needs them.
+// Numerically this is the same computation in a different association (verified against autograd in fp64 to 1e-15 in the
+// prototype the tests restate); in bf16 mode it is more accurate than the recomputing path, which rounds dz to bf16.
+#pragma once
+#include "gemm_core.h"
+#include "conv_tiles.h"
+
+namespace emb {
+
+// layout of a partial / total row (floats)
+constexpr int kGramG0 = 0;                       // [4][128]        G0[ci][tap * 8 + c2]
+constexpr int kGramP = 512;                      // [2][7][15][16]  P(u, d) at the head (which = 0: position u) / tail (position L - 1 - u)
+constexpr int kGramColS = kGramP + 2 * 7 * 15 * 16;   // [8][4]     column sums of x, 8 chunks of 32 positions
+constexpr int kGramEdgeS = kGramColS + 64;       // [2][7][4]       x at the head / tail positions
+constexpr int kGramRow = 4096;                   // floats per row (3992 used)
+constexpr int kGramMaxK = 15, kGramEdge = 7;     // taps, edge positions (k <= 15)
+constexpr int kGramOnesCol = 120;                // column of G0 that holds sum_r x~[r - pad][ci] = colTot - TailS[pad] (k * 8 <= 120)
+
+constexpr int kGramEdgeHead = 21, kGramEdgeTail = 7, kGramEdgeRows = (kGramEdgeHead + kGramEdgeTail) * 4;   // edge image rows (position, channel)
+constexpr int kGramPart = 512;                    // floats per PARTIAL row (one per statistics workgroup): the G0 block only
+constexpr int kGramJobs = 2 * kGramEdge * kGramMaxK + 2 * kGramEdge + kGramPart / 16;   // 210 edge products, 14 edge sums, 32 G0 column blocks
+
+// one tile of the statistics pass.  xs: the staged tile [rows][8] bf16 (zero halos), row_off(row): LDS element offset of tile row `row`.
+// G0 on the matrix cores: A = x~[r - pad] (the tap-0 column block of the view), B = the view's column block(s) of this wave
+template <int NW, int NIW, int UNR, typename RowOff>
+__device__ __forceinline__ void gram_tile(const __bf16* xs, RowOff row_off, f32x4 (&accg)[NIW], int L, int SB, int slot, int lane, int wave) {
+  typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
+  const int g = lane >> 4, r16 = lane & 15, q4 = r16 >> 2, p4 = r16 & 3;
+#pragma unroll UNR
+  for (int ks = 0; ks < 256 / 32; ++ks) {
+    const int ra = ks * 32 + 8 * g + q4;
+    const int x0 = row_off(ra), x1 = row_off(ra + 4);
+    const int zrow = SB * slot * 8;                          // A operand: rows past the tile's sequences read a zero row
+    union { struct { s16x4 lo, hi; } s; bf16x8 v; } ua;
+    ua.s.lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(xs + (ra < SB * L ? x0 : zrow) + 4 * p4));
+    ua.s.hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(xs + (ra + 4 < SB * L ? x1 : zrow) + 4 * p4));
+#pragma unroll
+    for (int ni = 0; ni < NIW; ++ni) {
+      const int xoff = (ni * NW + wave) * 16 + 4 * p4;
+      union { struct { s16x4 lo, hi; } s; bf16x8 v; } ub;
+      ub.s.lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(xs + x0 + xoff));
+      ub.s.hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(xs + x1 + xoff));
+      if (ni * NW + wave == kGramOnesCol / 16 && r16 == kGramOnesCol % 16) {   // a column of ones: G0[ci][120] = sum_r x~[r - pad][ci]
+#pragma unroll
+        for (int e = 0; e < 8; ++e) ub.v[e] = (__bf16)1.0f;
+      }
+      accg[ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ua.v, ub.v, accg[ni], 0, 0, 0);
+    }
+  }
+}
+
+template <int NW, int NIW>
+__device__ __forceinline__ void gram_store(float* row, const f32x4 (&accg)[NIW], int lane, int wave) {
+  const int g = lane >> 4, r16 = lane & 15;
+  if (g == 0) {                                             // accumulator rows 0..3 = input channels 0..3
+#pragma unroll
+    for (int ni = 0; ni < NIW; ++ni)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) row[kGramG0 + r * 128 + (ni * NW + wave) * 16 + r16] = accg[ni][r];
+  }
+}
+
+// The edge image E[row][b] (bf16, b contiguous): row = j * 4 + ch for the head positions j = 0..20 and (21 + j) * 4 + ch for the tail
+// positions L - 7 + j, j = 0..6; zero where the position is outside the sequence.  The statistics pass writes it from its staged
+// tiles (112 two-byte stores per sequence); the edge jobs below then read whole lines of it instead of one position per line of x.
+__device__ __forceinline__ void gram_edge_store(const __bf16* xs, __bf16* edge, int B, int L, int slot, int pad, int b0, int nseq) {
+  const int t = threadIdx.x;
+  if (t >= kGramEdgeRows) return;
+  const int j = t >> 2, ch = t & 3, pos = j < kGramEdgeHead ? j : L - kGramEdgeTail + (j - kGramEdgeHead);
+  for (int sq = 0; sq < nseq; ++sq)
+    edge[(long)t * B + b0 + sq] = (pos >= 0 && pos < L) ? xs[(sq * slot + pos + pad) * 8 + ch] : (__bf16)0.0f;
+}
+
+// Totals of the lag statistics, written by the apply pass's prologue: job j of kGramJobs (workgroups take jobs j = wg, wg + nwg, ..)
+//   j < 210        P(which, u, d) = sum_b x_b[pos] (x) x_b[pos + d], pos = u (head) or L - 1 - u (tail): eight rows of the edge image,
+//                  the threads walk the batch, sixteen sums meet wave-wise and then across the waves in wave order
+//   210 <= j < 224 x at the edge positions, summed over the batch
+//   224 <= j       sixteen columns of G0: column sums of the statistics pass's partial rows
+struct GramEdgeJob {          // decoded edge job: image rows of x[pos] and x[pos + d]
+  int ja, jb;                 // jb < 0: no partner (edge sums), or the partner lies past the sequence (the products are zero)
+  bool prod, live;
+};
+__device__ __forceinline__ GramEdgeJob gram_edge_job(int job, int L) {
+  constexpr int NP = 2 * kGramEdge * kGramMaxK;
+  GramEdgeJob j;
+  j.prod = job < NP;
+  int which, u, d = 0;
+  if (j.prod) {
+    which = job / (kGramEdge * kGramMaxK);
+    const int rem = job - which * kGramEdge * kGramMaxK;
+    u = rem / kGramMaxK; d = rem - u * kGramMaxK;
+  } else {
+    which = (job - NP) / kGramEdge; u = (job - NP) - which * kGramEdge;
+  }
+  // head: u + d <= 20 always inside the image; tail: pos + d <= L - 1 iff d <= u
+  j.ja = which ? kGramEdgeHead + (kGramEdgeTail - 1 - u) : u;
+  j.jb = !j.prod ? -1 : which ? (d <= u ? j.ja + d : -1) : u + d;
+  j.live = u < L && (!j.prod || j.jb >= 0);
+  return j;
+}
+// two sequences per thread and load (B even): the eight loads of a job's first chunk are issued early (before the BatchNorm
+// finalisation of the same prologue) and consumed by gram_job
+struct GramPre { uint32_t va[4], vb[4]; bool have; };
+template <int NTHR>
+__device__ __forceinline__ GramPre gram_job_preload(int job, const __bf16* __restrict__ edge, int B, int L) {
+  GramPre r;
+  r.have = false;
+#pragma unroll
+  for (int c = 0; c < 4; ++c) { r.va[c] = 0u; r.vb[c] = 0u; }
+  if (job >= 2 * kGramEdge * kGramMaxK + 2 * kGramEdge || (B & 1)) return r;
+  const GramEdgeJob j = gram_edge_job(job, L);
+  r.have = true;
+  const int b2 = threadIdx.x;
+  if (!j.live || 2 * b2 >= B) return r;
+  const uint32_t* ea = reinterpret_cast<const uint32_t*>(edge + (long)j.ja * 4 * B);
+  const uint32_t* eb = reinterpret_cast<const uint32_t*>(edge + (long)(j.jb < 0 ? j.ja : j.jb) * 4 * B);
+#pragma unroll
+  for (int c = 0; c < 4; ++c) { r.va[c] = ea[(long)c * (B >> 1) + b2]; r.vb[c] = eb[(long)c * (B >> 1) + b2]; }
+  return r;
+}
+
+template <int NTHR>
+__device__ __forceinline__ void gram_job(int job, const GramPre& pre, const __bf16* __restrict__ edge, int B, int L, const float* __restrict__ part,
+                                         int rows, float* __restrict__ tot, float* scratch) {
+  constexpr int NP = 2 * kGramEdge * kGramMaxK, NE = 2 * kGramEdge, NWV = NTHR / 64;
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  if (job < NP + NE) {
+    const GramEdgeJob j = gram_edge_job(job, L);
+    const bool prod = j.prod;
+    float p[16];
+#pragma unroll
+    for (int e = 0; e < 16; ++e) p[e] = 0.0f;
+    auto fma16 = [&](const float (&xa)[4], const float (&xb)[4]) {
+#pragma unroll
+      for (int c1 = 0; c1 < 4; ++c1)
+#pragma unroll
+        for (int c2 = 0; c2 < 4; ++c2) p[c1 * 4 + c2] += prod ? xa[c1] * xb[c2] : (c2 == 0 ? xa[c1] : 0.0f);
+    };
+    auto pair16 = [&](const uint32_t (&va)[4], const uint32_t (&vb)[4]) {   // sequences 2 * b2 (low halves) and 2 * b2 + 1, in that order
+      float xa[4], xb[4];
+#pragma unroll
+      for (int c = 0; c < 4; ++c) { xa[c] = __uint_as_float(va[c] << 16); xb[c] = __uint_as_float(vb[c] << 16); }
+      fma16(xa, xb);
+#pragma unroll
+      for (int c = 0; c < 4; ++c) { xa[c] = __uint_as_float(va[c] & 0xFFFF0000u); xb[c] = __uint_as_float(vb[c] & 0xFFFF0000u); }
+      fma16(xa, xb);
+    };
+    if (j.live) {
+      const __bf16* ea = edge + (long)j.ja * 4 * B;
+      const __bf16* eb = edge + (long)(j.jb < 0 ? j.ja : j.jb) * 4 * B;
+      if (!(B & 1)) {
+        int b2 = t;
+        if (pre.have) { pair16(pre.va, pre.vb); b2 += NTHR; }   // (lanes past the batch preloaded zeros)
+        for (; 2 * b2 < B; b2 += NTHR) {
+          uint32_t va[4], vb[4];
+#pragma unroll
+          for (int c = 0; c < 4; ++c) {
+            va[c] = reinterpret_cast<const uint32_t*>(ea)[(long)c * (B >> 1) + b2];
+            vb[c] = reinterpret_cast<const uint32_t*>(eb)[(long)c * (B >> 1) + b2];
+          }
+          pair16(va, vb);
+        }
+      } else {
+        for (int b = t; b < B; b += NTHR) {
+          float xa[4], xb[4];
+#pragma unroll
+          for (int c = 0; c < 4; ++c) { xa[c] = (float)ea[(long)c * B + b]; xb[c] = (float)eb[(long)c * B + b]; }
+          fma16(xa, xb);
+        }
+      }
+    }
+    // sixteen sums: within each row of 16 lanes by DPP (no LDS round trips), then the 4 * NWV row sums in row order
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+      const float r = row16_sum<float>(p[e]);
+      if ((lane & 15) == 0) scratch[e * (4 * NWV) + wave * 4 + (lane >> 4)] = r;
+    }
+    __syncthreads();
+    if (t < 16) {
+      float s = 0.0f;
+      for (int w = 0; w < 4 * NWV; ++w) s += scratch[t * (4 * NWV) + w];
+      if (prod) tot[kGramP + job * 16 + t] = s;
+      else if ((t & 3) == 0) tot[kGramEdgeS + (job - NP) * 4 + (t >> 2)] = s;   // (sum slot c1 * 4: the edge value of channel c1)
+    }
+    __syncthreads();
+    return;
+  }
+  // G0 column block: thread (row group rg, column c): rows rg, rg + G, ..; the groups meet in group order
+  constexpr int G = NTHR / 16;
+  const int c = (job - NP - NE) * 16 + (t & 15), rg = t >> 4;
+  float acc = 0.0f;
+  int r = rg;
+  for (; r + 7 * G < rows; r += 8 * G) {                    // eight rows in flight
+    float v[8];
+#pragma unroll
+    for (int q = 0; q < 8; ++q) v[q] = part[(long)(r + q * G) * kGramPart + c];
+#pragma unroll
+    for (int q = 0; q < 8; ++q) acc += v[q];
+  }
+  for (; r < rows; r += G) acc += part[(long)r * kGramPart + c];
+  scratch[rg * 16 + (t & 15)] = acc;
+  __syncthreads();
+  if (t < 16) {
+    float s = 0.0f;
+    for (int q = 0; q < G; ++q) s += scratch[q * 16 + t];
+    tot[kGramG0 + c] = s;
+  }
+  __syncthreads();
+}
+
+}  // namespace emb
+
+namespace emb {
+
+struct FirstFinArgs {
+  const float* slab;        // [S][C][KK + 1]: A partials (column KK = sum of g)
+  const float* gram;        // [kGramRow] totals
+  const __bf16* w;          // [C][KK] packed weights (tap-major, 8 input channels per tap, what the forward multiplied with)
+  const float* bias;        // [C]
+  const float* stats;       // [4][C] mean, invstd, scale, shift
+  float* dW;                // [C][Cin][k]  (torch layout)
+  float* dbias;             // [C]
+  float* dgamma;
+  float* dbeta;
+  int S, C, k, Cin, pad, training;
+  double count;             // rows behind the batch statistics (B * L)
+};
+
+// one workgroup per output channel, thread m = column (tap, ci) of the weight-gradient row (first_gram.h, top)
+__global__ __launch_bounds__(1024) void first_bwd_finish_kernel(const FirstFinArgs a) {
+  __shared__ float G[kGramRow];                    // totals
+  __shared__ float Hd[8 * kGramMaxK * 16];         // Head[j][d][c1][c2], j = 0..7
+  __shared__ float Tl[8 * kGramMaxK * 16];         // Tail[j][d][c1][c2]
+  __shared__ float HS[8 * 4], TS[8 * 4], colT[4];
+  __shared__ float Ar[128], Wr[128], red[4], As[8][128];
+  const int c = blockIdx.x, KK = a.k * 8, k = a.k, pad = a.pad;
+  for (int i = threadIdx.x; i < kGramRow; i += 1024) G[i] = a.gram[i];
+  {   // A[c][m] = sum over the slices: eight slice groups x 128 columns, sixteen loads in flight, groups meet in group order
+    const int m = threadIdx.x & 127, sgp = threadIdx.x >> 7;
+    float s = 0.0f;
+    if (m <= KK) {
+      const float* src = a.slab + (long)c * (KK + 1) + m;
+      const long stride = (long)a.C * (KK + 1);
+      int i = sgp;
+      for (; i + 15 * 8 < a.S; i += 16 * 8) {
+        float v[16];
+#pragma unroll
+        for (int j = 0; j < 16; ++j) v[j] = src[(long)(i + j * 8) * stride];
+#pragma unroll
+        for (int j = 0; j < 16; ++j) s += v[j];
+      }
+      for (; i < a.S; i += 8) s += src[(long)i * stride];
+    }
+    As[sgp][m] = s;
+  }
+  __syncthreads();
+  if (threadIdx.x >= 128) return;
+  const int t = threadIdx.x;
+  Ar[t] = ((As[0][t] + As[1][t]) + (As[2][t] + As[3][t])) + ((As[4][t] + As[5][t]) + (As[6][t] + As[7][t]));
+  Wr[t] = t < KK ? (float)a.w[(long)c * KK + t] : 0.0f;
+  // prefix sums over the edge positions: Head[j] = sum_{u < j} P_head(u), Tail[j] = sum_{v < j} P_tail(v)
+  for (int i = t; i < kGramMaxK * 16; i += 128) {   // i = d * 16 + c1 * 4 + c2
+    float h = 0.0f, tl = 0.0f;
+    Hd[i] = 0.0f; Tl[i] = 0.0f;
+#pragma unroll
+    for (int j = 1; j <= kGramEdge; ++j) {
+      h += G[kGramP + ((0 * kGramEdge + (j - 1)) * kGramMaxK) * 16 + i];
+      tl += G[kGramP + ((1 * kGramEdge + (j - 1)) * kGramMaxK) * 16 + i];
+      Hd[j * kGramMaxK * 16 + i] = h;
+      Tl[j * kGramMaxK * 16 + i] = tl;
+    }
+  }
+  if (t < 4) {
+    float h = 0.0f, tl = 0.0f;
+    HS[t] = 0.0f; TS[t] = 0.0f;
+    for (int j = 1; j <= kGramEdge; ++j) {
+      h += G[kGramEdgeS + (0 * kGramEdge + (j - 1)) * 4 + t];
+      tl += G[kGramEdgeS + (1 * kGramEdge + (j - 1)) * 4 + t];
+      HS[j * 4 + t] = h;
+      TS[j * 4 + t] = tl;
+    }
+    colT[t] = G[kGramG0 + t * 128 + kGramOnesCol] + TS[pad * 4 + t];   // (the ones column sums positions 0 .. L - 1 - pad)
+  }
+  // sum_m W[c][m] A[c][m]
+  float part = t < KK ? Wr[t] * Ar[t] : 0.0f;
+#pragma unroll
+  for (int m = 32; m >= 1; m >>= 1) part += __shfl_xor(part, m, 64);
+  if ((t & 63) == 0) red[t >> 6] = part;
+  __syncthreads();
+  const float dotWA = red[0] + red[1], sg = Ar[KK];
+  const float mean = a.stats[c], inv = a.stats[a.C + c], sc = a.stats[2 * a.C + c], b = a.bias[c];
+  const float gz = dotWA + b * sg;                 // sum g z
+  const float gx = inv * (gz - mean * sg);         // sum g xhat = dgamma
+  const float m1 = (float)((double)sg / a.count), m2 = (float)((double)gx / a.count);
+  if (t == 0) {
+    a.dgamma[c] = gx;
+    a.dbeta[c] = sg;
+    a.dbias[c] = a.training ? 0.0f : sc * sg;     // (behind training-mode BatchNorm the bias gradient is exactly zero)
+  }
+  if (t < KK) {
+    const int t2 = t >> 3, c2 = t & 7;
+    if (c2 < a.Cin) {
+      float dw = sc * Ar[t];
+      if (a.training) {
+        const int h2 = max(0, t2 - pad), l2 = max(0, pad - t2);
+        const float sx = colT[c2] - HS[h2 * 4 + c2] - TS[l2 * 4 + c2];
+        float wm = 0.0f;                           // sum_{m'} W[c][m'] M[m'][m]
+        for (int t1 = 0; t1 < k; ++t1) {
+          const bool up = t1 <= t2;                // d >= 0: block (t1, t2) as stored; else its transpose
+          const int d = up ? t2 - t1 : t1 - t2, te = up ? t1 : t2;
+          const int hj = max(0, te - pad), lj = max(0, pad - te);
+#pragma unroll
+          for (int c1 = 0; c1 < 4; ++c1) {
+            const int ab = up ? c1 * 4 + c2 : c2 * 4 + c1;                 // (c1, c2) of the stored block
+            const int ga = up ? c1 : c2, gb = up ? c2 : c1;
+            const float tot = G[kGramG0 + ga * 128 + d * 8 + gb] + Tl[(pad * kGramMaxK + d) * 16 + ab];
+            const float mel = tot - Hd[(hj * kGramMaxK + d) * 16 + ab] - Tl[(lj * kGramMaxK + d) * 16 + ab];
+            wm += Wr[t1 * 8 + c1] * mel;
+          }
+        }
+        dw = sc * (Ar[t] - m1 * sx - m2 * inv * (wm + (b - mean) * sx));
+      }
+      a.dW[((long)c * a.Cin + c2) * k + t2] = dw;
+    }
+  }
+}
+
+}  // namespace emb

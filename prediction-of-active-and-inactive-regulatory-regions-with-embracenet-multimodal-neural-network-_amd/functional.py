@@ -714,7 +714,7 @@ class _ConvStackFn(torch.autograd.Function):
             # first block with a few-channel input: recomputed in every pass instead of stored (csrc/conv_first.hip)
             fused = i == 0 and L_.emb_convblock_needs_y(B, L, cin_pad, Cout, k, code) == 0
             y = None if fused else torch.empty(B, L, Cout, dtype=T, device=dev)
-            stats = torch.empty(4, Cout, dtype=P, device=dev)
+            stats = torch.empty(L_.emb_convblock_stats_elems(B, L, cin_pad, Cout, k, code), dtype=P, device=dev)   # (+ lag statistics, first block)
             out = torch.empty((B, Cout, Lp) if last else (B, Lp, Cout), dtype=T, device=dev)
             argmax = torch.empty(B, Lp, Cout, dtype=torch.uint8, device=dev)
             nbytes = L_.emb_convblock_workspace_bytes(B, L, cin_pad, Cout, k, code)
