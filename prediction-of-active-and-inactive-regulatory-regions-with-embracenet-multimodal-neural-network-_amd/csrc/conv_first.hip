@@ -969,14 +969,34 @@ int conv_first_bwd_acc(const void* dout, int dout_ncl, const uint8_t* argmax, co
   return first_launch<F_BACC>(a, gm, s);
 }
 
-// ... and the per-channel finish: slab sums, lag statistics, weights -> dW (torch layout), dbias, dgamma, dbeta
+// ... and the per-channel finish: slab sums, lag statistics, weights -> dW (torch layout), dbias, dgamma, dbeta.  In a deferring
+// training step (emb_reduce_defer) the job is parked: the optimizer launch runs it as its first workgroups (first_fin.h)
 int conv_first_bwd_finish(const void* slab, int slices, const float* gram_tot, const void* w, const void* bias, const void* stats, void* dW,
                           void* dbias, void* dgamma, void* dbeta, int training, int B, int L, int Cin, int Cout, int k, hipStream_t s) {
   FirstFinArgs f{};
   f.slab = (const float*)slab; f.gram = gram_tot; f.w = (const __bf16*)w; f.bias = (const float*)bias; f.stats = (const float*)stats;
   f.dW = (float*)dW; f.dbias = (float*)dbias; f.dgamma = (float*)dgamma; f.dbeta = (float*)dbeta;
   f.S = slices; f.C = Cout; f.k = k; f.Cin = Cin; f.pad = (k - 1) / 2; f.training = training; f.count = (double)B * L;
-  first_bwd_finish_kernel<<<Cout, 1024, 0, s>>>(f);
+  return first_fin_submit(f, s);
+}
+
+struct FirstFinStore {
+  const FirstFinArgs& a;
+  int c;
+  __device__ __forceinline__ void scalars(float dgamma, float dbeta, float dbias) const {
+    a.dgamma[c] = dgamma; a.dbeta[c] = dbeta; a.dbias[c] = dbias;
+  }
+  __device__ __forceinline__ void dw(long idx, float v) const { a.dW[idx] = v; }
+};
+
+// one workgroup per output channel
+__global__ __launch_bounds__(1024) void first_bwd_finish_kernel(const FirstFinArgs a) {
+  __shared__ float lds[first_finish_lds_floats<1024>()];
+  first_finish_body<1024>(a, (int)blockIdx.x, lds, FirstFinStore{a, (int)blockIdx.x});
+}
+
+int first_fin_launch(const FirstFinArgs& f, hipStream_t s) {
+  first_bwd_finish_kernel<<<f.C, 1024, 0, s>>>(f);
   EMB_CHECK_LAUNCH();
   return EMB_OK;
 }

@@ -1,0 +1,30 @@
+// The per-channel finish of the first conv block's recompute-free backward (first_gram.h): its argument block, and the slot in which
+// a training step parks it so that the optimizer launch can run it as extra workgroups (loss_optim.hip) instead of a launch
+// of its own.
+#pragma once
+#include "common.h"
+
+namespace emb {
+
+struct FirstFinArgs {
+  const float* slab;        // [S][C][KK + 1]: A partials (column KK = sum of g)
+  const float* gram;        // [kGramRow] totals
+  const __bf16* w;          // [C][KK] packed weights (tap-major, 8 input channels per tap, what the forward multiplied with)
+  const float* bias;        // [C]
+  const float* stats;       // [4][C] mean, invstd, scale, shift
+  float* dW;                // [C][Cin][k]  (torch layout)
+  float* dbias;             // [C]
+  float* dgamma;
+  float* dbeta;
+  int S, C, k, Cin, pad, training;
+  double count;             // rows behind the batch statistics (B * L)
+};
+
+// deferred mode (emb_reduce_defer): parks the job (one slot; a second submit launches the first); else launches the finish kernel
+int first_fin_submit(const FirstFinArgs& f, hipStream_t s);
+bool first_fin_peek(FirstFinArgs* out);      // the parked job, if any (stays parked)
+void first_fin_drop();                       // the optimizer launch took it over
+int first_fin_flush(hipStream_t s);          // launches a parked job the classic way (emb_reduce_flush, or an optimizer call that cannot take it)
+int first_fin_launch(const FirstFinArgs& f, hipStream_t s);   // conv_first.hip
+
+}  // namespace emb

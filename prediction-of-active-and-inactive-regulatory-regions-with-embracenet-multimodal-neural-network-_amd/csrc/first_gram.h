@@ -22,6 +22,7 @@
 #pragma once
 #include "gemm_core.h"
 #include "conv_tiles.h"
+#include "first_fin.h"
 
 namespace emb {
 
@@ -230,98 +231,116 @@ __device__ __forceinline__ void gram_job(int job, const GramPre& pre, const __bf
 
 namespace emb {
 
-struct FirstFinArgs {
-  const float* slab;        // [S][C][KK + 1]: A partials (column KK = sum of g)
-  const float* gram;        // [kGramRow] totals
-  const __bf16* w;          // [C][KK] packed weights (tap-major, 8 input channels per tap, what the forward multiplied with)
-  const float* bias;        // [C]
-  const float* stats;       // [4][C] mean, invstd, scale, shift
-  float* dW;                // [C][Cin][k]  (torch layout)
-  float* dbias;             // [C]
-  float* dgamma;
-  float* dbeta;
-  int S, C, k, Cin, pad, training;
-  double count;             // rows behind the batch statistics (B * L)
-};
+constexpr int kGramUsed = kGramEdgeS + 2 * kGramEdge * 4;   // floats of a totals row in use
+constexpr int kFinFixed = kGramUsed + 4 + 128 + 128 + 4;   // floats of LDS before As
+template <int NTHR> constexpr int first_finish_lds_floats() { return kFinFixed + (NTHR / 128) * 128; }
 
-// one workgroup per output channel, thread m = column (tap, ci) of the weight-gradient row (first_gram.h, top)
-__global__ __launch_bounds__(1024) void first_bwd_finish_kernel(const FirstFinArgs a) {
-  __shared__ float G[kGramRow];                    // totals
-  __shared__ float Hd[8 * kGramMaxK * 16];         // Head[j][d][c1][c2], j = 0..7
-  __shared__ float Tl[8 * kGramMaxK * 16];         // Tail[j][d][c1][c2]
-  __shared__ float HS[8 * 4], TS[8 * 4], colT[4];
-  __shared__ float Ar[128], Wr[128], red[4], As[8][128];
-  const int c = blockIdx.x, KK = a.k * 8, k = a.k, pad = a.pad;
-  for (int i = threadIdx.x; i < kGramRow; i += 1024) G[i] = a.gram[i];
-  {   // A[c][m] = sum over the slices: eight slice groups x 128 columns, sixteen loads in flight, groups meet in group order
-    const int m = threadIdx.x & 127, sgp = threadIdx.x >> 7;
+// The per-channel finish of the recompute-free backward (top of this file): channel c, NTHR threads (a multiple of 128), `lds`
+// = first_finish_lds_floats<NTHR>() floats.  Results go to `sink`: sink.scalars(dgamma, dbeta, dbias) once (thread 0) and
+// sink.dw(index into the torch-layout weight [C][Cin][k], value) for every real weight of the channel -- the standalone kernel
+// stores them, the optimizer launch (loss_optim.hip) updates the parameters with them on the spot.
+template <int NTHR, typename Sink>
+__device__ __forceinline__ void first_finish_body(const FirstFinArgs& a, const int c, float* lds, Sink&& sink) {
+  constexpr int NG = NTHR / 128, NPd = kGramMaxK * 16;   // slice groups of the slab sum; (d, c1, c2) entries per edge position
+  float* G0 = lds + kGramG0;                              // the totals row, verbatim: G0 [4][128],
+  float* PP = lds + kGramP;                               // [2][7][15][16] P totals -> inclusive prefix sums over the edge position,
+  float* ES = lds + kGramEdgeS;                           // [2][7][4] edge sums -> inclusive prefix sums
+  float* colT = lds + kGramUsed;                          // [4]
+  float* Ar = colT + 4;                                   // [128]
+  float* Wr = Ar + 128;                                   // [128]
+  float* red = Wr + 128;                                  // [4]
+  float* As = red + 4;                                    // [NG][128]
+  const int KK = a.k * 8, k = a.k, pad = a.pad, tid = threadIdx.x;
+  // wide variant (the standalone kernel): the totals travel through registers, in flight during the slab sum; narrow variant
+  // (inside the optimizer launch, whose other workgroups want few registers): a plain copy first, eight slab loads in flight
+  constexpr bool WIDE = NTHR >= 1024;
+  constexpr int NGV = WIDE ? (kGramUsed + NTHR - 1) / NTHR : 1, NIF = WIDE ? 16 : 8;
+  float gtot[NGV];
+  if (WIDE) {
+#pragma unroll
+    for (int q = 0; q < NGV; ++q) gtot[q] = tid + q * NTHR < kGramUsed ? a.gram[tid + q * NTHR] : 0.0f;
+  } else {
+    for (int i = tid; i < kGramUsed; i += NTHR) lds[i] = a.gram[i];
+  }
+  {   // A[c][m] = sum over the slices: NG slice groups x 128 columns, sixteen loads in flight, groups meet in group order
+    const int m = tid & 127, sgp = tid >> 7;
     float s = 0.0f;
     if (m <= KK) {
       const float* src = a.slab + (long)c * (KK + 1) + m;
       const long stride = (long)a.C * (KK + 1);
       int i = sgp;
-      for (; i + 15 * 8 < a.S; i += 16 * 8) {
-        float v[16];
+      for (; i + (NIF - 1) * NG < a.S; i += NIF * NG) {
+        float v[NIF];
 #pragma unroll
-        for (int j = 0; j < 16; ++j) v[j] = src[(long)(i + j * 8) * stride];
+        for (int j = 0; j < NIF; ++j) v[j] = src[(long)(i + j * NG) * stride];
 #pragma unroll
-        for (int j = 0; j < 16; ++j) s += v[j];
+        for (int j = 0; j < NIF; ++j) s += v[j];
       }
-      for (; i < a.S; i += 8) s += src[(long)i * stride];
+      for (; i < a.S; i += NG) s += src[(long)i * stride];
     }
-    As[sgp][m] = s;
+    As[sgp * 128 + m] = s;
+  }
+  if (WIDE) {
+#pragma unroll
+    for (int q = 0; q < NGV; ++q)
+      if (tid + q * NTHR < kGramUsed) lds[tid + q * NTHR] = gtot[q];
   }
   __syncthreads();
-  if (threadIdx.x >= 128) return;
-  const int t = threadIdx.x;
-  Ar[t] = ((As[0][t] + As[1][t]) + (As[2][t] + As[3][t])) + ((As[4][t] + As[5][t]) + (As[6][t] + As[7][t]));
-  Wr[t] = t < KK ? (float)a.w[(long)c * KK + t] : 0.0f;
-  // prefix sums over the edge positions: Head[j] = sum_{u < j} P_head(u), Tail[j] = sum_{v < j} P_tail(v)
-  for (int i = t; i < kGramMaxK * 16; i += 128) {   // i = d * 16 + c1 * 4 + c2
-    float h = 0.0f, tl = 0.0f;
-    Hd[i] = 0.0f; Tl[i] = 0.0f;
+  // prefix sums over the edge positions, in place: PP[which][u] := sum_{u' <= u} P(which, u'), likewise the edge sums
+  for (int i = tid; i < 2 * NPd; i += NTHR) {
+    const int which = i / NPd, e = i - which * NPd;
+    float run = 0.0f;
 #pragma unroll
-    for (int j = 1; j <= kGramEdge; ++j) {
-      h += G[kGramP + ((0 * kGramEdge + (j - 1)) * kGramMaxK) * 16 + i];
-      tl += G[kGramP + ((1 * kGramEdge + (j - 1)) * kGramMaxK) * 16 + i];
-      Hd[j * kGramMaxK * 16 + i] = h;
-      Tl[j * kGramMaxK * 16 + i] = tl;
+    for (int u = 0; u < kGramEdge; ++u) {
+      run += PP[(which * kGramEdge + u) * NPd + e];
+      PP[(which * kGramEdge + u) * NPd + e] = run;
     }
   }
-  if (t < 4) {
-    float h = 0.0f, tl = 0.0f;
-    HS[t] = 0.0f; TS[t] = 0.0f;
-    for (int j = 1; j <= kGramEdge; ++j) {
-      h += G[kGramEdgeS + (0 * kGramEdge + (j - 1)) * 4 + t];
-      tl += G[kGramEdgeS + (1 * kGramEdge + (j - 1)) * 4 + t];
-      HS[j * 4 + t] = h;
-      TS[j * 4 + t] = tl;
+  if (tid >= NTHR - 8) {
+    const int i = tid - (NTHR - 8), which = i >> 2, ch = i & 3;
+    float run = 0.0f;
+    for (int u = 0; u < kGramEdge; ++u) {
+      run += ES[(which * kGramEdge + u) * 4 + ch];
+      ES[(which * kGramEdge + u) * 4 + ch] = run;
     }
-    colT[t] = G[kGramG0 + t * 128 + kGramOnesCol] + TS[pad * 4 + t];   // (the ones column sums positions 0 .. L - 1 - pad)
   }
+  if (tid < 128) {
+    float s = 0.0f;
+#pragma unroll
+    for (int q = 0; q < NG; ++q) s += As[q * 128 + tid];
+    Ar[tid] = s;
+    Wr[tid] = tid < KK ? (float)a.w[(long)c * KK + tid] : 0.0f;
+  }
+  __syncthreads();
+  // Head[j] = sum_{u < j} P_head(u), Tail[j] = sum_{v < j} P_tail(v): j = 0 is the empty sum
+  auto Hd = [&](int j, int e) { return j ? PP[((0 * kGramEdge + j - 1)) * NPd + e] : 0.0f; };
+  auto Tl = [&](int j, int e) { return j ? PP[((1 * kGramEdge + j - 1)) * NPd + e] : 0.0f; };
+  auto HS = [&](int j, int ch) { return j ? ES[(0 * kGramEdge + j - 1) * 4 + ch] : 0.0f; };
+  auto TS = [&](int j, int ch) { return j ? ES[(1 * kGramEdge + j - 1) * 4 + ch] : 0.0f; };
+  if (tid >= 128) return;
+  const int t = tid;
   // sum_m W[c][m] A[c][m]
   float part = t < KK ? Wr[t] * Ar[t] : 0.0f;
-#pragma unroll
-  for (int m = 32; m >= 1; m >>= 1) part += __shfl_xor(part, m, 64);
+  part = row16_sum<float>(part);
+  part += __shfl_xor(part, 16, 64);
+  part += __shfl_xor(part, 32, 64);
   if ((t & 63) == 0) red[t >> 6] = part;
-  __syncthreads();
-  const float dotWA = red[0] + red[1], sg = Ar[KK];
+  // (read before the barrier: the sink of thread 0 may UPDATE the bias parameter in place)
   const float mean = a.stats[c], inv = a.stats[a.C + c], sc = a.stats[2 * a.C + c], b = a.bias[c];
+  __syncthreads();   // (all 128 remaining threads: two whole waves)
+  const float dotWA = red[0] + red[1], sg = Ar[KK];
   const float gz = dotWA + b * sg;                 // sum g z
   const float gx = inv * (gz - mean * sg);         // sum g xhat = dgamma
   const float m1 = (float)((double)sg / a.count), m2 = (float)((double)gx / a.count);
-  if (t == 0) {
-    a.dgamma[c] = gx;
-    a.dbeta[c] = sg;
-    a.dbias[c] = a.training ? 0.0f : sc * sg;     // (behind training-mode BatchNorm the bias gradient is exactly zero)
-  }
+  if (t == 0) sink.scalars(gx, sg, a.training ? 0.0f : sc * sg);   // (behind training-mode BatchNorm the bias gradient is exactly zero)
   if (t < KK) {
     const int t2 = t >> 3, c2 = t & 7;
     if (c2 < a.Cin) {
       float dw = sc * Ar[t];
       if (a.training) {
         const int h2 = max(0, t2 - pad), l2 = max(0, pad - t2);
-        const float sx = colT[c2] - HS[h2 * 4 + c2] - TS[l2 * 4 + c2];
+        // the ones column of G0 sums positions 0 .. L - 1 - pad
+        const float sx = (G0[c2 * 128 + kGramOnesCol] + TS(pad, c2)) - HS(h2, c2) - TS(l2, c2);
         float wm = 0.0f;                           // sum_{m'} W[c][m'] M[m'][m]
         for (int t1 = 0; t1 < k; ++t1) {
           const bool up = t1 <= t2;                // d >= 0: block (t1, t2) as stored; else its transpose
@@ -331,14 +350,14 @@ __global__ __launch_bounds__(1024) void first_bwd_finish_kernel(const FirstFinAr
           for (int c1 = 0; c1 < 4; ++c1) {
             const int ab = up ? c1 * 4 + c2 : c2 * 4 + c1;                 // (c1, c2) of the stored block
             const int ga = up ? c1 : c2, gb = up ? c2 : c1;
-            const float tot = G[kGramG0 + ga * 128 + d * 8 + gb] + Tl[(pad * kGramMaxK + d) * 16 + ab];
-            const float mel = tot - Hd[(hj * kGramMaxK + d) * 16 + ab] - Tl[(lj * kGramMaxK + d) * 16 + ab];
+            const float tot = G0[ga * 128 + d * 8 + gb] + Tl(pad, d * 16 + ab);
+            const float mel = tot - Hd(hj, d * 16 + ab) - Tl(lj, d * 16 + ab);
             wm += Wr[t1 * 8 + c1] * mel;
           }
         }
         dw = sc * (Ar[t] - m1 * sx - m2 * inv * (wm + (b - mean) * sx));
       }
-      a.dW[((long)c * a.Cin + c2) * k + t2] = dw;
+      sink.dw(((long)c * a.Cin + c2) * k + t2, dw);
     }
   }
 }

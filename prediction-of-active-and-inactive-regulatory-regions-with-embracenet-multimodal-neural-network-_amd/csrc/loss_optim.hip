@@ -292,6 +292,7 @@ extern "C" int emb_counter_add(uint64_t* counter, uint64_t inc, emb_stream_t str
 #include <unordered_map>
 #include "reduce.h"
 #include "rider.h"
+#include "first_gram.h"
 namespace emb {
 int launch_jobs_f32(const ReduceJob* jobs, int n, hipStream_t s);   // reduce.hip
 int launch_jobs_f64(const ReduceJob* jobs, int n, hipStream_t s);
@@ -327,6 +328,11 @@ template <typename P> struct MultiArgs {
   long long* stats_conf[2];
   int nstats;
   int count;
+  // the parked finish of the first conv block's recompute-free backward (first_fin.h): its C channels run as the FIRST nff
+  // workgroups of the launch and update the block's four tensors themselves (ff_t: weight, bias, gamma, beta; -1: not ours)
+  FirstFinArgs ff;
+  int nff;
+  signed char ff_t[4];
 };
 static_assert(sizeof(MultiArgs<float>) + 128 <= 4096, "kernel argument block");
 enum { OPT_ADAM = 0, OPT_RMSPROP = 1, OPT_NADAM = 2 };
@@ -426,10 +432,10 @@ __global__ __launch_bounds__(256) void multi_opt_kernel(const MultiArgs<P> args,
     for (int i = threadIdx.x; i < (int)(sizeof(MultiArgs<P>) / 4); i += 256) dst[i] = src[i];
   }
   __syncthreads();
-  const int bid = (int)blockIdx.x;
+  const int bid = (int)blockIdx.x - a.nff;
   const int plain_end = a.blk_end[a.count - 1];
   const int slab_end = a.nsrc ? a.slab[a.nsrc - 1].blk_end : plain_end;
-  if (bid >= slab_end) {     // statistics sums: one block per job, slices split over the 256 threads
+  if (bid >= 0 && bid >= slab_end) {     // statistics sums: one block per job, slices split over the 256 threads
     const int k = bid - slab_end;
     const SlabSrc& sj = a.stats[k];
     const P* in = (const P*)sj.in;
@@ -465,6 +471,28 @@ __global__ __launch_bounds__(256) void multi_opt_kernel(const MultiArgs<P> args,
   kc.pb1 = (P)h.b1; kc.pb2 = (P)h.b2; kc.omb1 = (P)(1.0 - h.b1); kc.omb2 = (P)(1.0 - h.b2); kc.pwd = (P)h.wd; kc.peps = (P)h.eps;
   kc.pa = (P)h.alpha; kc.oma = (P)(1.0 - h.alpha); kc.plr = (P)h.lr;
 
+  if constexpr (sizeof(P) == 4) {
+    if (bid < 0) {            // finish of the first conv block's backward for channel blockIdx.x, parameters updated on the spot
+      __shared__ float fin_lds[first_finish_lds_floats<256>()];
+      struct Sink {
+        const MultiArgs<P>& a;
+        const OptConst<P>& kc;
+        int c;
+        __device__ __forceinline__ void one(int which, long idx, float v, float* fallback) const {
+          const int t = a.ff_t[which];
+          if (t < 0) { if (fallback) fallback[idx] = v; return; }
+          a.g[t][idx] = v;       // the parameter's .grad holds the gradient, as after the standalone finish
+          opt_update<P, OPT>(a, kc, t, idx, v);
+        }
+        __device__ __forceinline__ void scalars(float dgamma, float dbeta, float dbias) const {
+          one(2, c, dgamma, a.ff.dgamma); one(3, c, dbeta, a.ff.dbeta); one(1, c, dbias, a.ff.dbias);
+        }
+        __device__ __forceinline__ void dw(long idx, float v) const { one(0, idx, v, a.ff.dW); }
+      };
+      first_finish_body<256>(a.ff, (int)blockIdx.x, fin_lds, Sink{a, kc, (int)blockIdx.x});
+      return;
+    }
+  }
   if (bid < plain_end) {      // a tensor whose gradient is a plain tensor
     int t = 0;
     while (t < a.count - 1 && bid >= a.blk_end[t]) ++t;
@@ -546,6 +574,25 @@ static int multi_launch(void* const* params, const void* const* grads, void* con
     memset(&a, 0, sizeof(a));
     long long blocks = 0;
     int nsrc = 0;
+    // a parked first-block finish (first_fin.h) rides in this launch when its weight, gamma and beta gradients are tensors of it
+    int fft[4] = {-1, -1, -1, -1};
+    FirstFinArgs ffj{};
+    bool have_ff = false;
+    if (sizeof(P) == 4 && first_fin_peek(&ffj)) {
+      for (int i = 0; i < cnt; ++i) {
+        const void* gp = grads[off + i];
+        if (gp == nullptr) continue;
+        if (gp == ffj.dW) fft[0] = i; else if (gp == ffj.dbias) fft[1] = i; else if (gp == ffj.dgamma) fft[2] = i; else if (gp == ffj.dbeta) fft[3] = i;
+      }
+      have_ff = fft[0] >= 0 && fft[2] >= 0 && fft[3] >= 0 && ffj.C <= 1024;
+      if (have_ff) {
+        first_fin_drop();
+      } else {
+        const int rcf = first_fin_flush(s);   // not ours: the classic launch
+        if (rcf != EMB_OK) return rcf;
+        fft[0] = fft[1] = fft[2] = fft[3] = -1;
+      }
+    }
     for (int i = 0; i < kMaxTensors; ++i) {
       const int j = off + (i < cnt ? i : 0);
       a.p[i] = (P*)params[j];
@@ -556,6 +603,7 @@ static int multi_launch(void* const* params, const void* const* grads, void* con
       a.flip[i] = nullptr;
       a.pk_k[i] = a.pk_cin[i] = a.pk_cinpad[i] = a.pk_cout[i] = 0;
       bool plain = true;
+      if (have_ff && i < cnt && (i == fft[0] || i == fft[1] || i == fft[2] || i == fft[3])) plain = false;   // updated by the finish workgroups
       if (i < cnt) {
         if (sizes[j] >= (1ll << 31)) { set_error("optimizer step: tensor of %lld elements", (long long)sizes[j]); return EMB_ERR_ARG; }
         if (sizeof(P) == 4) {
@@ -571,7 +619,7 @@ static int multi_launch(void* const* params, const void* const* grads, void* con
         }
         // a queued slab reduction that would have produced this gradient: its slices are summed in this launch (reduce.h)
         ReduceClaim cl;
-        if (reduce_claim(grads[j], sizeof(P) == 8, &cl)) {
+        if (plain && reduce_claim(grads[j], sizeof(P) == 8, &cl)) {
           int k = -1;
           for (int q = 0; q < nsrc; ++q)
             if (a.slab[q].in == cl.job.in && a.slab[q].per == cl.job.per) k = q;
@@ -617,8 +665,14 @@ static int multi_launch(void* const* params, const void* const* grads, void* con
       a.stats_conf[a.nstats] = (long long*)sj.out[1];
       ++a.nstats;
     }
-    if (blocks == 0 && a.nstats == 0) continue;
-    multi_opt_kernel<P, OPT><<<(int)blocks + a.nstats, 256, 0, s>>>(a, h);
+    a.nff = 0;
+    if (have_ff) {
+      a.ff = ffj;
+      a.nff = ffj.C;
+      for (int q = 0; q < 4; ++q) a.ff_t[q] = (signed char)fft[q];
+    }
+    if (blocks == 0 && a.nstats == 0 && a.nff == 0) continue;
+    multi_opt_kernel<P, OPT><<<(int)blocks + a.nstats + a.nff, 256, 0, s>>>(a, h);
     EMB_CHECK_LAUNCH();
   }
   return EMB_OK;

@@ -2,6 +2,7 @@
 #include <vector>
 
 #include "reduce.h"
+#include "first_fin.h"
 #include "rider.h"
 
 namespace emb {
@@ -172,6 +173,28 @@ int launch_jobs_f64(const ReduceJob* jobs, int n, hipStream_t s) { return launch
 
 bool reduce_deferring() { return g_defer; }
 
+// ---- the parked finish of the first conv block's recompute-free backward (first_fin.h)
+static FirstFinArgs g_fin;
+static bool g_fin_valid = false;
+int first_fin_flush(hipStream_t s) {
+  if (!g_fin_valid) return EMB_OK;
+  g_fin_valid = false;
+  return first_fin_launch(g_fin, s);
+}
+int first_fin_submit(const FirstFinArgs& f, hipStream_t s) {
+  if (!g_defer) return first_fin_launch(f, s);
+  const int rc = first_fin_flush(s);   // (one slot)
+  if (rc != EMB_OK) return rc;
+  g_fin = f;
+  g_fin_valid = true;
+  return EMB_OK;
+}
+bool first_fin_peek(FirstFinArgs* out) {
+  if (g_fin_valid) *out = g_fin;
+  return g_fin_valid;
+}
+void first_fin_drop() { g_fin_valid = false; }
+
 int reduce_submit(const ReduceJob& job, bool is_double, hipStream_t s) {
   if (job.per <= 0 || job.S <= 0) return EMB_OK;
   if (g_defer) {
@@ -192,6 +215,8 @@ extern "C" int emb_reduce_defer(int on) {
 extern "C" int emb_reduce_flush(emb_stream_t stream) {
   emb::Pending& p = emb::pending();
   int rc = emb::rider_flush();   // a parked launch may be the producer of a queued slab
+  if (rc != EMB_OK) return rc;
+  rc = emb::first_fin_flush((hipStream_t)stream);
   if (rc != EMB_OK) return rc;
   if (!p.f32.empty()) rc = emb::launch_jobs<float>(p.f32.data(), (int)p.f32.size(), (hipStream_t)stream);
   if (rc == EMB_OK && !p.f64.empty()) rc = emb::launch_jobs<double>(p.f64.data(), (int)p.f64.size(), (hipStream_t)stream);

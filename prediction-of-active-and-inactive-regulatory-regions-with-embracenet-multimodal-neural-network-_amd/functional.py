@@ -335,6 +335,8 @@ def _parr(tensors):
 
 
 _RIDER_KEEP = []     # tensors a parked rider launch reads or writes: kept alive until the flush
+_FIN_KEEP = []       # BatchNorm vectors + lag statistics of the first conv block: its backward's finish may be parked until the
+                     # optimizer launch (csrc/first_fin.h) and reads them there; released when the next backward parks its own
 
 
 def rider_flush():
@@ -774,6 +776,8 @@ class _ConvStackFn(torch.autograd.Function):
                 if phase == 1:
                     sync(sums)                                       # {sum dz, sum dz*xhat, rows} -> of the global batch
             grads[6 * i:6 * i + 4] = [None if sk[j] is not None else g_ for j, g_ in enumerate((dW, db, dgam, dbeta))]
+            if fused:
+                _FIN_KEEP[:] = [stats]
             g = dx
         if _RIDER_KEEP:
             rider_flush()                      # a parked MLP backward that no kernel of this stack carried
