@@ -345,6 +345,9 @@ def step_accounting(wl, dims, ms_per_step, stats_csv):
         "first_stats": (["first_stats_rider_kernel", "first_kernel<2, 2, 0>"], c0["flops"] + (mlp_f[0] if rider else 0),
                         B * 4 * 256 * s + c0["x"] + (mlp_f[1] if rider else 0)),                # loader layout in, image out
         "first_apply": (["first_kernel<2, 2, 1>"], c0["flops"], c0["x"] + c0["pooled"] + c0["arg"]),   # recompute + BN/ReLU/pool out
+        # the recompute-free backward of block 1 (csrc/first_gram.h): ONE pass A = g^T xview (the weight-gradient contraction, no
+        # convolution) -- its per-channel finish runs inside the optimizer launch.  EMB_FIRST_LINEAR=0: the two recomputing passes.
+        "first_bwd_acc": (["first_kernel<2, 2, 4>"], c0["flops"], c0["x"] + c0["pooled"] + c0["arg"]),
         "first_bwd_sums": (["first_kernel<2, 2, 2>"], c0["flops"], c0["x"] + c0["pooled"] + c0["arg"]),   # recompute + window-space sums
         "first_bwd_wgrad": (["first_kernel<2, 2, 3>"], 2 * c0["flops"], c0["x"] + c0["pooled"] + c0["arg"]),   # recompute + weight gradient
         "embrace_fwd": (["embrace_fwd"], 2.0 * B * c * K, s * B * K + s * c * K + s * B * c + B * c),
@@ -370,6 +373,8 @@ def step_accounting(wl, dims, ms_per_step, stats_csv):
     if any("conv_bwd_dual_kernel" in n for n in rows) and "conv2_wgrad" in table:   # one launch for both gradients of block 2
         (_, f1, b1), (_, f2, b2) = table.pop("conv2_wgrad"), table.pop("conv2_dgrad")
         table["conv2_wgrad+dgrad"] = (["conv_bwd_dual_kernel"], f1 + f2, b1 + b2)
+    if rows:   # classes whose kernels did not run in this step (the other first-block backward)
+        table = {cls: v for cls, v in table.items() if not cls.startswith("first_bwd") or any(f in n for f in v[0] for n in rows)}
     kernels = {}
     for cls, (frags, fl, by) in table.items():
         us = next((v for f in frags for n, v in rows.items() if f in n), None)

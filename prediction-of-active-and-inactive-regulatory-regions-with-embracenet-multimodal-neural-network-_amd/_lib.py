@@ -66,6 +66,7 @@ SIGNATURES = {
     "emb_reduce_flush": [_vp],
     "emb_convblock_needs_y": [_i, _i, _i, _i, _i, _i],
     "emb_convblock_stats_elems": [_i, _i, _i, _i, _i, _i],
+    "emb_convblock_first_linear": [_i],
     "emb_cast": [_vp, _i, _vp, _i, _i64, _vp],
     "emb_counter_add": [_vp, _u64, _vp],
 }

@@ -672,9 +672,13 @@ template <typename T> static ConvWs conv_workspace(int B, int L, int cin_pad, in
 }
 
 // the recompute-free backward of the fused first block (first_gram.h) needs the forward to leave the lag statistics behind `stats`
+static int g_first_linear = -1;   // -1: not decided yet (environment EMB_FIRST_LINEAR=0 turns it off); emb_convblock_first_linear() sets it
 static bool first_linear_enabled() {
-  static const bool on = [] { const char* e = getenv("EMB_FIRST_LINEAR"); return !(e && e[0] == '0'); }();
-  return on;
+  if (g_first_linear < 0) {
+    const char* e = getenv("EMB_FIRST_LINEAR");
+    g_first_linear = !(e && e[0] == '0');
+  }
+  return g_first_linear != 0;
 }
 template <typename T> static bool first_linear(int training, int bn_phase) {
   return sizeof(T) == 2 && first_linear_enabled() && training && bn_phase == 0;
@@ -1040,6 +1044,12 @@ extern "C" int emb_convblock_fwd(const void* x, const void* wpack, const void* b
 
 extern "C" int64_t emb_convblock_stats_elems(int B, int L, int cin_pad, int Cout, int k, int dtype) {
   return 4 * (int64_t)Cout + ((dtype == EMB_BF16 && conv_first_supported(dtype, B, L, cin_pad, Cout, k)) ? conv_first_gram_floats() : 0);
+}
+
+extern "C" int emb_convblock_first_linear(int on) {
+  const int was = first_linear_enabled() ? 1 : 0;
+  if (on >= 0) g_first_linear = on != 0;
+  return was;
 }
 
 extern "C" int emb_convblock_needs_y(int B, int L, int cin_pad, int Cout, int k, int dtype) {

@@ -295,3 +295,48 @@ def test_loader_layout_staged_by_the_statistics_pass_equals_the_conversion_launc
     assert torch.equal(res[0][0], res[1][0])
     for a, b in zip(res[0][1] + res[0][2], res[1][1] + res[1][2]):
         assert torch.equal(a, b)
+
+
+@pytest.mark.parametrize("B,L,spec", [(40, 256, [(4, 64, 15), (64, 32, 15)]), (21, 37, [(4, 16, 5)]), (9, 100, [(4, 32, 11)]),
+                                      (33, 70, [(4, 64, 7), (64, 32, 3)])], ids=["a549", "short37", "one100", "short70"])
+def test_first_block_linear_backward_equals_the_recomputing_backward(ea, B, L, spec):
+    """bf16 first block: the recompute-free backward (csrc/first_gram.h: dW, dgamma, dbeta from A = g^T xview, the lag statistics
+    of the input and the weights) against the two recomputing passes it replaces, on a REAL-valued input (the lag statistics must
+    not rely on one-hot rows) and against autograd in fp64.  Both GPU paths see the same bf16 inputs and round the dense gradient
+    tile to bf16 once, in different places: they agree with each other far more closely (measured 2e-3 .. 2e-2 of the largest
+    gradient) than either agrees with fp64 arithmetic on bf16 activations."""
+    L_ = ea._lib.lib()
+    x = torch.from_numpy(dg.uniform(f"lin/{B}/{L}/x", (B, 4, L), -1.0, 1.0)).to(torch.bfloat16).double()
+    ref_blocks = [Blk(f"lin/{B}/{i}", ci, co, k, torch.float64) for i, (ci, co, k) in enumerate(spec)]
+    with torch.no_grad():
+        for b in ref_blocks:
+            b.conv.weight.copy_(b.conv.weight.to(torch.bfloat16).double())
+    out_ref = reference(x, ref_blocks, True)
+    dout = torch.from_numpy(dg.uniform(f"lin/{B}/dout", tuple(out_ref.shape), -1, 1)).to(torch.bfloat16).double()
+    out_ref.backward(dout)
+
+    def run(linear):
+        was = L_.emb_convblock_first_linear(int(linear))
+        try:
+            blocks = [Blk(f"lin/{B}/{i}", ci, co, k, torch.float32) for i, (ci, co, k) in enumerate(spec)]
+            for b in blocks:
+                b.conv.to(DEV); b.bn.to(DEV)
+            layers = [dict(conv=b.conv, bn=b.bn, drop_p=0.0, layer_id=4 + i) for i, b in enumerate(blocks)]
+            out = ea.functional.conv_stack(x.to(DEV, torch.float32), layers, True, compute_dtype=torch.bfloat16)
+            out.backward(dout.to(DEV, torch.bfloat16))
+            torch.cuda.synchronize()
+            return out.double().cpu(), [p.grad.double().cpu() for p in blocks[0].params()]
+        finally:
+            L_.emb_convblock_first_linear(was)
+    out_l, g_l = run(True)
+    out_r, g_r = run(False)
+    assert torch.equal(out_l, out_r)                       # the forward is the same computation in both modes
+    ref = [p.grad for p in ref_blocks[0].params()]
+    for nm, a, b, r in zip(("w", "b", "gamma", "beta"), g_l, g_r, ref):
+        if nm == "b":
+            assert a.abs().max().item() == 0.0               # exactly zero behind training-mode BatchNorm
+            continue
+        s = max(1e-3, r.abs().max().item())
+        e_lin, e_rec = (a - r).abs().max().item() / s, (b - r).abs().max().item() / s
+        assert e_lin < TOL["bf16"] * 20 and e_rec < TOL["bf16"] * 20, (nm, e_lin, e_rec)
+        assert (a - b).abs().max().item() / s < 5e-2, (nm, "paths disagree", (a - b).abs().max().item() / s)
