@@ -359,8 +359,8 @@ def step_accounting(wl, dims, ms_per_step, stats_csv):
     if len(convs) > 1:
         c1 = convs[1]
         table.update({
-            "conv2_fwd": (["conv_t_stream_kernel<2, 2, true>", "conv_t_kernelIDF16bLi2"], c1["flops"], c1["x"] + c1["y"]),
-            "conv2_dgrad": (["conv_t_stream_kernel<4, 1, false>", "conv_t_kernelIDF16bLi4"], c1["flops"], c1["y"] + c1["x"]),
+            "conv2_fwd": (["conv_t_stream_kernel<2, 2, true", "conv_t_kernelIDF16bLi2"], c1["flops"], c1["x"] + c1["y"]),
+            "conv2_dgrad": (["conv_t_stream_kernel<4, 1, false", "conv_t_kernelIDF16bLi4"], c1["flops"], c1["y"] + c1["x"]),
             "conv2_wgrad": (["conv_wgrad_stream", "conv_wgrad_direct"], c1["flops"], c1["y"] + c1["x"]),
             "bn_relu_pool": (["bn_relu_pool"], 0.0, c1["y"] + c1["pooled"] + c1["arg"]),
             "bn_bwd_dz": (["bn_bwd_dz"], (mlp_b[0] if rider else 0.0), c1["pooled"] + c1["arg"] + 2 * c1["y"] + (mlp_b[1] if rider else 0)),
