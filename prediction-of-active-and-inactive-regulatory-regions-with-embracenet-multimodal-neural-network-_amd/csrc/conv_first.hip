@@ -98,7 +98,7 @@ __device__ __forceinline__ void first_body(const FirstArgs& a, const int bm) {
   constexpr int ZP = BN + 8;                            // pitch of the row-major bf16 tile (BN+ReLU output / dz)
   extern __shared__ __attribute__((aligned(16))) char arena[];
   const int L = a.L, Lp = a.Lp, C = a.C, SB = a.SB, slot = a.slot, KK = a.KK;
-  const int xrows = SB * slot + kXExtra, nks = (KK + 31) / 32;
+  const int xrows = SB * slot + kXExtra;
   // LDS carve
   constexpr int DPP = BN + 8, AMP = BN + 8;             // pitches of the pooled-gradient rows (bf16) / argmax rows (bytes)
   T* xs = reinterpret_cast<T*>(arena);                                 // [xrows][8]
@@ -173,17 +173,21 @@ __device__ __forceinline__ void first_body(const FirstArgs& a, const int bm) {
   if (tm_begin < tm_end) issue_x(tm_begin);
 
   // ---- weights (A operand, channel-permuted rows) and per-channel constants of this lane's CPL channels
-  const int kl = 8 * g;
-  bf16x8 wf[MT][4];
+  // The tile keeps 8 channels per position (4 real + 4 zero: 16-byte rows) but the convolution contracts only the real ones: a
+  // k-step of 32 = EIGHT taps x 4 channels (lane group g: taps 8*ks + 2g and + 1, one 8-byte read each), half the MFMAs and LDS
+  // bytes of four-taps-times-eight.  The weight fragments are gathered to match from the packed [C][k][8] rows.
+  constexpr int NKS = 2;                                 // k <= 15 -> 4k <= 64
+  const int nks = (4 * a.KK / 8 + 31) / 32;
+  bf16x8 wf[MT][NKS];
 #pragma unroll
   for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
-    for (int ks = 0; ks < 4; ++ks) {
-      const int ch = gcol + chan_of<T, MT>(mt, r16), kk = ks * 32 + kl;
-      bf16x8 f;
-#pragma unroll
-      for (int e = 0; e < 8; ++e) f[e] = (T)0.0f;
-      if (ch < C && kk < KK) f = *reinterpret_cast<const bf16x8*>(a.w + (long)ch * KK + kk);
+    for (int ks = 0; ks < NKS; ++ks) {
+      const int ch = gcol + chan_of<T, MT>(mt, r16), t0 = ks * 8 + 2 * g;
+      bf16x4 lo = {(T)0.0f, (T)0.0f, (T)0.0f, (T)0.0f}, hi = lo;
+      if (ch < C && t0 * 8 < KK) lo = *reinterpret_cast<const bf16x4*>(a.w + (long)ch * KK + t0 * 8);
+      if (ch < C && (t0 + 1) * 8 < KK) hi = *reinterpret_cast<const bf16x4*>(a.w + (long)ch * KK + (t0 + 1) * 8);
+      bf16x8 f = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
       wf[mt][ks] = f;
     }
   // ---- BatchNorm vectors: from global memory, or finalised here from the producer's partial rows (bn_inline.h)
@@ -274,6 +278,7 @@ __device__ __forceinline__ void first_body(const FirstArgs& a, const int bm) {
   const bool gram = MODE == F_STATS && a.gram_part != nullptr;
   // weight-gradient accumulators: all MIW channel tiles x this wave's n-blocks (16 columns of k*8) nb = ni*NW + wave
   constexpr int MIW = MT * CH, NIW = 8 / NW;
+  constexpr int kBaccNB = 4, MIWB = MIW / (NW / kBaccNB);   // F_BACC: four compact column blocks, the waves of a block share the channel tiles
   typename Mm::AccV accw[BW ? MIW : 1][NIW];
   if (BW) {
 #pragma unroll
@@ -471,12 +476,16 @@ __device__ __forceinline__ void first_body(const FirstArgs& a, const int bm) {
 #pragma unroll
           for (int r = 0; r < 4; ++r) acc[mt][j][r] = 0;
 #pragma unroll
-      for (int ks = 0; ks < (MODE == F_BACC ? 0 : 4); ++ks) {   // (F_BACC needs no convolution)
+      for (int ks = 0; ks < (MODE == F_BACC ? 0 : NKS); ++ks) {   // (F_BACC needs no convolution)
         if (ks < nks) {
           bf16x8 bf[2];
 #pragma unroll
-          for (int j = 0; j < 2; ++j)                  // cin == 8: k-step ks, lane-group g reads tap 4*ks + g: one LDS row
-            bf[j] = *reinterpret_cast<const bf16x8*>(xs + (xrow_h[j] + 4 * ks + g) * XS);
+          for (int j = 0; j < 2; ++j) {                // k-step ks, lane group g: the four real channels of taps 8*ks + 2g and + 1
+            const T* xp = xs + (xrow_h[j] + 8 * ks + 2 * g) * XS;
+            const bf16x4 lo = *reinterpret_cast<const bf16x4*>(xp), hi = *reinterpret_cast<const bf16x4*>(xp + XS);
+            bf16x8 v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+            bf[j] = v;
+          }
 #pragma unroll
           for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
@@ -683,7 +692,38 @@ __device__ __forceinline__ void first_body(const FirstArgs& a, const int bm) {
     }
 
     FIRST_T(2 + (tm - tm_begin) * 8 + 4);
-    if (BW) {
+    if (MODE == F_BACC) {
+      __syncthreads();
+      // A[o][n'] += sum_r g[r][o] * xview[r][n'] over the REAL input channels only: column n' = tap * 4 + ci (the transposing read
+      // of a lane takes the four real channels of tap nb * 4 + p4), 4 k <= 64 columns = four 16-column blocks instead of eight.
+      // Wave = (block nb, half mh of the channel tiles).  Column 4 k is forced to ones: sum_r g = dbeta.
+      const int nbb = (4 * a.KK / 8) >> 4, lane_b = (4 * a.KK / 8) & 15;
+      const int nb = wave % kBaccNB, mh = wave / kBaccNB, xoff = (nb * 4 + p4) * XS;
+#pragma unroll 2
+      for (int ks = 0; ks < kFBT / 32; ++ks) {
+        const int ra = ks * 32 + 8 * g + q4;
+        bf16x8 af[MIWB];
+#pragma unroll
+        for (int mi = 0; mi < MIWB; ++mi) {
+          const T* a0 = zt + ra * ZP + (mh * MIWB + mi) * 16 + 4 * p4;
+          union { struct { s16x4 lo, hi; } s; bf16x8 v; } u;
+          u.s.lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(a0));
+          u.s.hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(a0 + 4 * ZP));
+          af[mi] = u.v;
+        }
+        const int x0 = row_off(ra), x1 = row_off(ra + 4);
+        union { struct { s16x4 lo, hi; } s; bf16x8 v; } ub;
+        ub.s.lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(xs + x0 + xoff));
+        ub.s.hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(xs + x1 + xoff));
+        if (nb == nbb && r16 == lane_b) {
+#pragma unroll
+          for (int e = 0; e < 8; ++e) ub.v[e] = (T)1.0f;
+        }
+#pragma unroll
+        for (int mi = 0; mi < MIWB; ++mi) accw[mi][0] = Mm::mma(af[mi], ub.v, accw[mi][0]);
+      }
+    }
+    if (MODE == F_BWGRAD) {
       __syncthreads();
       // dW[o][n] += sum_r dz[r][o] * xview[r][n]:  A = dz^T (tr16 reads of the row-major tile), B = x view, K = 256 rows.
       // column KK of the B operand is forced to ones: slab column KK = sum_r dz = bias gradient
@@ -765,7 +805,18 @@ __device__ __forceinline__ void first_body(const FirstArgs& a, const int bm) {
             ((red[(0 * 2 + which) * BN + c] + red[(1 * 2 + which) * BN + c]) + red[(2 * 2 + which) * BN + c]) + red[(3 * 2 + which) * BN + c];
     }
   }
-  if (BW) {
+  if (MODE == F_BACC) {
+    float* dst = a.slab + (long)bm * C * kFinCols;      // [C][64]: the compact columns as they are (first_fin.h)
+    const int nb = wave % kBaccNB, mh = wave / kBaccNB, np = nb * 16 + r16;
+#pragma unroll
+    for (int mi = 0; mi < MIWB; ++mi)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int o = (mh * MIWB + mi) * 16 + Mm::acc_row(lane, r);
+        if (o < C) dst[(long)o * kFinCols + np] = accw[mi][0][r];
+      }
+  }
+  if (MODE == F_BWGRAD) {
     float* dst = a.slab + (long)bm * C * (KK + 1);
 #pragma unroll
     for (int mi = 0; mi < MIW; ++mi)

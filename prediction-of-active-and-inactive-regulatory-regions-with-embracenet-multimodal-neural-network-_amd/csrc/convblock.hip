@@ -663,6 +663,10 @@ template <typename T> static ConvWs conv_workspace(int B, int L, int cin_pad, in
   w.bwd_partial = al((size_t)w.nblk_bwd * 2 * Cout * sizeof(P));
   w.coef = al((size_t)2 * Cout * sizeof(P));
   w.slab = al((size_t)S * Cout * (KK + 1) * sizeof(P));
+  if (sizeof(T) == 2 && conv_first_supported(dtype_code<T>(), B, L, cin_pad, Cout, k)) {   // accumulate pass of the fused first block: 64-float rows
+    const size_t acc = al((size_t)conv_first_blocks(B, L, cin_pad, Cout, k) * Cout * 64 * sizeof(float));
+    if (acc > w.slab) w.slab = acc;
+  }
   // fused first block in bf16: per-workgroup partial lag statistics of the input (first_gram.h), after the statistics partials
   w.gram = (sizeof(T) == 2 && conv_first_supported(dtype_code<T>(), B, L, cin_pad, Cout, k))
                ? al(conv_first_gram_part_bytes(B, L, cin_pad, Cout, k)) : 0;
@@ -813,7 +817,8 @@ static int convblock_bwd(const void* dout, int dout_ncl, const uint8_t* argmax, 
     EMB_CHECK_ARG(conv_first_supported(dtype_code<T>(), B, L, cin_pad, Cout, k) && dx == nullptr && wpack && bias,
                   "emb_convblock_bwd: y == NULL needs the fused first block (emb_convblock_needs_y() == 0), wpack, bias and no dx");
     const int nb = conv_first_blocks(B, L, cin_pad, Cout, k);
-    EMB_CHECK_ARG((size_t)nb * 2 * Cout * sizeof(P) <= w.bwd_partial && (size_t)nb * Cout * (KK + 1) * sizeof(P) <= w.slab,
+    EMB_CHECK_ARG((size_t)nb * 2 * Cout * sizeof(P) <= w.bwd_partial && (size_t)nb * Cout * (KK + 1) * sizeof(P) <= w.slab &&
+                      (size_t)nb * Cout * 64 * sizeof(float) <= w.slab,
                   "emb_convblock_bwd: workspace layout too small for the fused first block");
     int rows = 0, S = 0, rc = EMB_OK;
     if (first_linear<T>(training, bn_phase)) {   // one pass A = g^T xview + a per-channel finish: no convolution, no sums pass (first_gram.h)

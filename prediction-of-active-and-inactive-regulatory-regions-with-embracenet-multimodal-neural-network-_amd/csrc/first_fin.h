@@ -7,7 +7,7 @@
 namespace emb {
 
 struct FirstFinArgs {
-  const float* slab;        // [S][C][KK + 1]: A partials (column KK = sum of g)
+  const float* slab;        // [S][C][64]: A partials, compact columns tap * 4 + ci (4 real input channels), column 4 k = sum of g
   const float* gram;        // [kGramRow] totals
   const __bf16* w;          // [C][KK] packed weights (tap-major, 8 input channels per tap, what the forward multiplied with)
   const float* bias;        // [C]

@@ -234,7 +234,8 @@ namespace emb {
 
 constexpr int kGramUsed = kGramEdgeS + 2 * kGramEdge * 4;   // floats of a totals row in use
 constexpr int kFinFixed = kGramUsed + 4 + 128 + 128 + 4;   // floats of LDS before As
-template <int NTHR> constexpr int first_finish_lds_floats() { return kFinFixed + (NTHR / 128) * 128; }
+constexpr int kFinCols = 64;                       // floats per slab row of the accumulate pass: 4 k compact columns + sum of g, k <= 15
+template <int NTHR> constexpr int first_finish_lds_floats() { return kFinFixed + NTHR; }
 
 // The per-channel finish of the recompute-free backward (top of this file): channel c, NTHR threads (a multiple of 128), `lds`
 // = first_finish_lds_floats<NTHR>() floats.  Results go to `sink`: sink.scalars(dgamma, dbeta, dbias) once (thread 0) and
@@ -242,7 +243,7 @@ template <int NTHR> constexpr int first_finish_lds_floats() { return kFinFixed +
 // stores them, the optimizer launch (loss_optim.hip) updates the parameters with them on the spot.
 template <int NTHR, typename Sink>
 __device__ __forceinline__ void first_finish_body(const FirstFinArgs& a, const int c, float* lds, Sink&& sink) {
-  constexpr int NG = NTHR / 128, NPd = kGramMaxK * 16;   // slice groups of the slab sum; (d, c1, c2) entries per edge position
+  constexpr int NG = NTHR / kFinCols, NPd = kGramMaxK * 16;   // slice groups of the slab sum; (d, c1, c2) entries per edge position
   float* G0 = lds + kGramG0;                              // the totals row, verbatim: G0 [4][128],
   float* PP = lds + kGramP;                               // [2][7][15][16] P totals -> inclusive prefix sums over the edge position,
   float* ES = lds + kGramEdgeS;                           // [2][7][4] edge sums -> inclusive prefix sums
@@ -250,7 +251,7 @@ __device__ __forceinline__ void first_finish_body(const FirstFinArgs& a, const i
   float* Ar = colT + 4;                                   // [128]
   float* Wr = Ar + 128;                                   // [128]
   float* red = Wr + 128;                                  // [4]
-  float* As = red + 4;                                    // [NG][128]
+  float* As = red + 4;                                    // [NG][kFinCols]
   const int KK = a.k * 8, k = a.k, pad = a.pad, tid = threadIdx.x;
   // wide variant (the standalone kernel): the totals travel through registers, in flight during the slab sum; narrow variant
   // (inside the optimizer launch, whose other workgroups want few registers): a plain copy first, eight slab loads in flight
@@ -263,12 +264,13 @@ __device__ __forceinline__ void first_finish_body(const FirstFinArgs& a, const i
   } else {
     for (int i = tid; i < kGramUsed; i += NTHR) lds[i] = a.gram[i];
   }
-  {   // A[c][m] = sum over the slices: NG slice groups x 128 columns, sixteen loads in flight, groups meet in group order
-    const int m = tid & 127, sgp = tid >> 7;
+  {   // A[c][n'] = sum over the slices (compact columns n' = tap * 4 + ci, 4 k = sum of g; kFinCols per slab row): NG slice groups
+      // x 64 columns, NIF loads in flight, the groups meet in group order
+    const int m = tid & (kFinCols - 1), sgp = tid / kFinCols;
     float s = 0.0f;
-    if (m <= KK) {
-      const float* src = a.slab + (long)c * (KK + 1) + m;
-      const long stride = (long)a.C * (KK + 1);
+    if (m <= 4 * k) {
+      const float* src = a.slab + (long)c * kFinCols + m;
+      const long stride = (long)a.C * kFinCols;
       int i = sgp;
       for (; i + (NIF - 1) * NG < a.S; i += NIF * NG) {
         float v[NIF];
@@ -279,7 +281,7 @@ __device__ __forceinline__ void first_finish_body(const FirstFinArgs& a, const i
       }
       for (; i < a.S; i += NG) s += src[(long)i * stride];
     }
-    As[sgp * 128 + m] = s;
+    As[sgp * kFinCols + m] = s;
   }
   if (WIDE) {
 #pragma unroll
@@ -305,10 +307,13 @@ __device__ __forceinline__ void first_finish_body(const FirstFinArgs& a, const i
       ES[(which * kGramEdge + u) * 4 + ch] = run;
     }
   }
-  if (tid < 128) {
+  if (tid < 128) {   // Ar: the padded column index the weights use (tap * 8 + ci; KK = sum of g), zero in the pad columns
+    const int tap = tid >> 3, ci = tid & 7, src = tid == KK ? 4 * k : (tid < KK && ci < 4 ? tap * 4 + ci : -1);
     float s = 0.0f;
+    if (src >= 0) {
 #pragma unroll
-    for (int q = 0; q < NG; ++q) s += As[q * 128 + tid];
+      for (int q = 0; q < NG; ++q) s += As[q * kFinCols + src];
+    }
     Ar[tid] = s;
     Wr[tid] = tid < KK ? (float)a.w[(long)c * KK + tid] : 0.0f;
   }
