@@ -94,7 +94,6 @@ __device__ __forceinline__ void first_body(const FirstArgs& a, const int bm) {
   typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
   constexpr int CPL = 4 * MT, GW = 16 * MT, BN = GW * CH, XS = 8, NW = 4 * CH, NTHR = 256 * CH;
   constexpr bool BW = MODE == F_BWGRAD || MODE == F_BACC;   // passes that build a dense gradient tile and run the weight-gradient MFMAs
-  constexpr int NIW_G = 8 / NW;                         // column blocks of the lag-statistics MFMA per wave
   constexpr int ZP = BN + 8;                            // pitch of the row-major bf16 tile (BN+ReLU output / dz)
   extern __shared__ __attribute__((aligned(16))) char arena[];
   const int L = a.L, Lp = a.Lp, C = a.C, SB = a.SB, slot = a.slot, KK = a.KK;
@@ -205,7 +204,7 @@ __device__ __forceinline__ void first_body(const FirstArgs& a, const int bm) {
     }
     if (MODE == F_APPLY && a.gram_tot != nullptr) {   // totals of the lag statistics, one job per workgroup (first_gram.h)
       for (int job = bm; job < kGramJobs; job += (int)gridDim.x) {
-        gram_job<NTHR>(job, gpre, a.gram_edge, a.B, L, a.gram_part, a.gram_rows, a.gram_tot, reinterpret_cast<float*>(fin_scratch));
+        gram_job<NTHR>(job, gpre, a.gram_edge, a.B, L, a.gram_part, a.gram_rows, NW / 4, a.gram_tot, reinterpret_cast<float*>(fin_scratch));
         gpre.have = false;
       }
     }
@@ -270,11 +269,7 @@ __device__ __forceinline__ void first_body(const FirstArgs& a, const int bm) {
   };
   // lag statistics (first_gram.h): MFMA accumulator of G0 = x~[r - pad]^T . xview (this wave's column blocks), accumulated over the
   // workgroup's tiles
-  typename Mm::AccV accg[NIW_G];
-#pragma unroll
-  for (int ni = 0; ni < NIW_G; ++ni)
-#pragma unroll
-    for (int r = 0; r < 4; ++r) accg[ni][r] = 0;
+  typename Mm::AccV accg = {0, 0, 0, 0};
   const bool gram = MODE == F_STATS && a.gram_part != nullptr;
   // weight-gradient accumulators: all MIW channel tiles x this wave's n-blocks (16 columns of k*8) nb = ni*NW + wave
   constexpr int MIW = MT * CH, NIW = 8 / NW;
@@ -456,8 +451,8 @@ __device__ __forceinline__ void first_body(const FirstArgs& a, const int bm) {
     if (MODE == F_STATS) {   // (after the next tile's loads are in flight: this phase hides their latency)
       if (gram) {
         gram_edge_store(xs, a.gram_edge, a.B, L, slot, a.pad, b0, nseq);
-        if (SB == 1) gram_tile<NW, NIW_G, 4>(xs, [&](int row) { return min(row, L - 1) * XS; }, accg, L, SB, slot, lane, wave);   // one sequence per tile: no division
-        else gram_tile<NW, NIW_G, 2>(xs, row_off, accg, L, SB, slot, lane, wave);
+        if (SB == 1) gram_tile<NW, 4>(xs, [&](int row) { return min(row, L - 1) * XS; }, accg, L, SB, slot, lane, wave);   // one sequence per tile: no division
+        else gram_tile<NW, 2>(xs, row_off, accg, L, SB, slot, lane, wave);
       }
     }
     FIRST_T(2 + (tm - tm_begin) * 8 + 1);
@@ -783,7 +778,7 @@ __device__ __forceinline__ void first_body(const FirstArgs& a, const int bm) {
     }
   }
   if (MODE == F_STATS) {
-    if (gram) gram_store<NW, NIW_G>(a.gram_part + (long)bm * kGramPart, accg, lane, wave);
+    if (gram) gram_store(a.gram_part + (long)bm * kGramPart, accg, lane, wave);
   }
   FIRST_T(42);
   if (MODE == F_STATS) {   // one partial row per workgroup

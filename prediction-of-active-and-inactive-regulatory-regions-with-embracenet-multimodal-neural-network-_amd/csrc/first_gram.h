@@ -41,42 +41,40 @@ constexpr int kGramPart = 512;                    // floats per PARTIAL row (one
 constexpr int kGramJobs = 2 * kGramEdge * kGramMaxK + 2 * kGramEdge + kGramPart / 16;   // 210 edge products, 14 edge sums, 32 G0 column blocks
 
 // one tile of the statistics pass.  xs: the staged tile [rows][8] bf16 (zero halos), row_off(row): LDS element offset of tile row `row`.
-// G0 on the matrix cores: A = x~[r - pad] (the tap-0 column block of the view), B = the view's column block(s) of this wave
-template <int NW, int NIW, int UNR, typename RowOff>
-__device__ __forceinline__ void gram_tile(const __bf16* xs, RowOff row_off, f32x4 (&accg)[NIW], int L, int SB, int slot, int lane, int wave) {
+// G0 on the matrix cores over the REAL channels: A = x~[r - pad] (the tap-0 block of the view), B = compact 16-column block nb of
+// the view (column n' = tap * 4 + c2: a lane's transposing read takes the four real channels of tap nb * 4 + p4), 64 columns =
+// four blocks.  Wave = (block nb, part kh of the k-steps): NW / 4 partial accumulators per block, stored side by side.
+constexpr int kGramOnesC = 60;                    // compact column forced to ones (4 k <= 60): G0[ci][60] = sum_r x~[r - pad][ci]
+template <int NW, int UNR, typename RowOff>
+__device__ __forceinline__ void gram_tile(const __bf16* xs, RowOff row_off, f32x4& accg, int L, int SB, int slot, int lane, int wave) {
   typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
+  constexpr int KSN = 8 / (NW / 4);                          // k-steps per wave
   const int g = lane >> 4, r16 = lane & 15, q4 = r16 >> 2, p4 = r16 & 3;
+  const int nb = wave & 3, ks0 = (wave >> 2) * KSN, xoff = (nb * 4 + p4) * 8;
 #pragma unroll UNR
-  for (int ks = 0; ks < 256 / 32; ++ks) {
+  for (int ks = ks0; ks < ks0 + KSN; ++ks) {
     const int ra = ks * 32 + 8 * g + q4;
     const int x0 = row_off(ra), x1 = row_off(ra + 4);
     const int zrow = SB * slot * 8;                          // A operand: rows past the tile's sequences read a zero row
-    union { struct { s16x4 lo, hi; } s; bf16x8 v; } ua;
+    union { struct { s16x4 lo, hi; } s; bf16x8 v; } ua, ub;
     ua.s.lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(xs + (ra < SB * L ? x0 : zrow) + 4 * p4));
     ua.s.hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(xs + (ra + 4 < SB * L ? x1 : zrow) + 4 * p4));
+    ub.s.lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(xs + x0 + xoff));
+    ub.s.hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(xs + x1 + xoff));
+    if (nb == kGramOnesC / 16 && r16 == kGramOnesC % 16) {
 #pragma unroll
-    for (int ni = 0; ni < NIW; ++ni) {
-      const int xoff = (ni * NW + wave) * 16 + 4 * p4;
-      union { struct { s16x4 lo, hi; } s; bf16x8 v; } ub;
-      ub.s.lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(xs + x0 + xoff));
-      ub.s.hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(xs + x1 + xoff));
-      if (ni * NW + wave == kGramOnesCol / 16 && r16 == kGramOnesCol % 16) {   // a column of ones: G0[ci][120] = sum_r x~[r - pad][ci]
-#pragma unroll
-        for (int e = 0; e < 8; ++e) ub.v[e] = (__bf16)1.0f;
-      }
-      accg[ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ua.v, ub.v, accg[ni], 0, 0, 0);
+      for (int e = 0; e < 8; ++e) ub.v[e] = (__bf16)1.0f;
     }
+    accg = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ua.v, ub.v, accg, 0, 0, 0);
   }
 }
 
-template <int NW, int NIW>
-__device__ __forceinline__ void gram_store(float* row, const f32x4 (&accg)[NIW], int lane, int wave) {
+// partial row: [NW / 4 parts][4 ci][64 n']
+__device__ __forceinline__ void gram_store(float* row, const f32x4& accg, int lane, int wave) {
   const int g = lane >> 4, r16 = lane & 15;
   if (g == 0) {                                             // accumulator rows 0..3 = input channels 0..3
 #pragma unroll
-    for (int ni = 0; ni < NIW; ++ni)
-#pragma unroll
-      for (int r = 0; r < 4; ++r) row[kGramG0 + r * 128 + (ni * NW + wave) * 16 + r16] = accg[ni][r];
+    for (int r = 0; r < 4; ++r) row[(wave >> 2) * 256 + r * 64 + (wave & 3) * 16 + r16] = accg[r];
   }
 }
 
@@ -95,7 +93,7 @@ __device__ __forceinline__ void gram_edge_store(const __bf16* xs, __bf16* edge, 
 //   j < 210        P(which, u, d) = sum_b x_b[pos] (x) x_b[pos + d], pos = u (head) or L - 1 - u (tail): eight rows of the edge image,
 //                  the threads walk the batch, sixteen sums meet wave-wise and then across the waves in wave order
 //   210 <= j < 224 x at the edge positions, summed over the batch
-//   224 <= j       sixteen columns of G0: column sums of the statistics pass's partial rows
+//   224 <= j       eight entries of G0: column sums of the statistics pass's partial rows (and of their `parts` k-step parts)
 struct GramEdgeJob {          // decoded edge job: image rows of x[pos] and x[pos + d]
   int ja, jb;                 // jb < 0: no partner (edge sums), or the partner lies past the sequence (the products are zero)
   bool prod, live;
@@ -141,7 +139,7 @@ __device__ __forceinline__ GramPre gram_job_preload(int job, const __bf16* __res
 
 template <int NTHR>
 __device__ __forceinline__ void gram_job(int job, const GramPre& pre, const __bf16* __restrict__ edge, int B, int L, const float* __restrict__ part,
-                                         int rows, float* __restrict__ tot, float* scratch) {
+                                         int rows, int parts, float* __restrict__ tot, float* scratch) {
   constexpr int NP = 2 * kGramEdge * kGramMaxK, NE = 2 * kGramEdge, NWV = NTHR / 64;
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
   if (job < NP + NE) {
@@ -205,25 +203,20 @@ __device__ __forceinline__ void gram_job(int job, const GramPre& pre, const __bf
     __syncthreads();
     return;
   }
-  // G0 column block: thread (row group rg, column c): rows rg, rg + G, ..; the groups meet in group order
-  constexpr int G = NTHR / 16;
-  const int c = (job - NP - NE) * 16 + (t & 15), rg = t >> 4;
+  // G0: eight of the 4 x 64 compact entries; thread (row group rg, entry): rows rg, rg + G, .. of every part; the groups meet in
+  // group order; the totals keep the padded column index the finish uses (tap * 8 + c2; the ones column -> kGramOnesCol)
+  constexpr int G = NTHR / 8;
+  const int o = (job - NP - NE) * 8 + (t & 7), rg = t >> 3;
   float acc = 0.0f;
-  int r = rg;
-  for (; r + 7 * G < rows; r += 8 * G) {                    // eight rows in flight
-    float v[8];
-#pragma unroll
-    for (int q = 0; q < 8; ++q) v[q] = part[(long)(r + q * G) * kGramPart + c];
-#pragma unroll
-    for (int q = 0; q < 8; ++q) acc += v[q];
-  }
-  for (; r < rows; r += G) acc += part[(long)r * kGramPart + c];
-  scratch[rg * 16 + (t & 15)] = acc;
+  for (int r = rg; r < rows; r += G)
+    for (int h = 0; h < parts; ++h) acc += part[(long)r * kGramPart + h * 256 + o];
+  scratch[rg * 8 + (t & 7)] = acc;
   __syncthreads();
-  if (t < 16) {
+  if (t < 8) {
     float s = 0.0f;
-    for (int q = 0; q < G; ++q) s += scratch[q * 16 + t];
-    tot[kGramG0 + c] = s;
+    for (int q = 0; q < G; ++q) s += scratch[q * 8 + t];
+    const int ci = o >> 6, np = o & 63;
+    tot[kGramG0 + ci * 128 + (np == kGramOnesC ? kGramOnesCol : (np >> 2) * 8 + (np & 3))] = s;
   }
   __syncthreads();
 }
