@@ -13,6 +13,7 @@
 // Arithmetic in fp32 on fp32 master weights; logits are rounded to the activation type T before the loss so that the loss
 // belongs to the logits the caller sees.
 #include "reduce.h"
+#include "conv_tiles.h"
 
 namespace emb {
 
@@ -56,9 +57,10 @@ template <> __device__ __forceinline__ void store4<__bf16>(__bf16* p, const floa
   *reinterpret_cast<bf4*>(p) = t;
 }
 
-__device__ __forceinline__ float wave_sum(float v) {
-#pragma unroll
-  for (int m = 32; m >= 1; m >>= 1) v += __shfl_xor(v, m, 64);   // butterfly: every lane ends with the same fixed-order sum
+__device__ __forceinline__ float wave_sum(float v) {   // every lane ends with the same fixed-order sum
+  v = row16_sum<float>(v);            // within the rows of 16 lanes by DPP (no LDS-crossbar round trips), then across the four rows
+  v += __shfl_xor(v, 16, 64);
+  v += __shfl_xor(v, 32, 64);
   return v;
 }
 
@@ -73,13 +75,15 @@ template <typename T, int KS> __global__ __launch_bounds__(256) void head_ce_ker
   // class counts of the whole batch (utils/utils.py:121-133): recounted per workgroup, fixed-order tree
   long long pl = 0;
   for (int i = tid; i < B; i += 256) pl += (a.target[i] == 1);
-  scount[tid] = pl;
-  __syncthreads();
-  for (int s = 128; s > 0; s >>= 1) {
-    if (tid < s) scount[tid] += scount[tid + s];
-    __syncthreads();
+  {   // integer sums: any order gives the same count; one barrier instead of a nine-barrier tree
+    int lo = (int)(pl & 0x7fffffff);             // (a thread sees at most B / 256 + 1 rows)
+    lo = row16_sum<int>(lo);
+    lo += __shfl_xor(lo, 16, 64);
+    lo += __shfl_xor(lo, 32, 64);
+    if (lane == 0) scount[wave] = lo;
   }
-  long long pos = scount[0], n = B;
+  __syncthreads();
+  long long pos = (scount[0] + scount[1]) + (scount[2] + scount[3]), n = B;
   if (a.global_counts) {
     pos = a.class_counts[0];
     n = a.class_counts[1];
