@@ -347,26 +347,37 @@ template <typename P> struct OptConst {
   P c1, c2, bc2s, pb1, pb2, omb1, omb2, pwd, peps, pa, oma, plr;
 };
 
-// update element i of tensor t with the (raw, weight-decay-free) gradient g
+// update element i of tensor t with the (raw, weight-decay-free) gradient g.  Two halves, so that a thread with several elements
+// can issue all its loads before the first store (parameter, state and gradient pointers may alias as far as the compiler knows:
+// element by element, every update would wait for the previous one's stores)
+template <typename P> struct OptElem { P p, m, v; };
 template <typename P, int OPT>
-__device__ __forceinline__ void opt_update(const MultiArgs<P>& a, const OptConst<P>& k, int t, long i, P graw) {
+__device__ __forceinline__ OptElem<P> opt_load(const MultiArgs<P>& a, int t, long i) {
+  OptElem<P> e;
+  e.p = a.p[t][i];
+  e.m = OPT == OPT_RMSPROP ? (P)0 : a.m[t][i];
+  e.v = a.v[t][i];
+  return e;
+}
+template <typename P, int OPT>
+__device__ __forceinline__ void opt_apply(const MultiArgs<P>& a, const OptConst<P>& k, int t, long i, P graw, const OptElem<P>& e) {
   P* p = a.p[t];
   P* m = a.m[t];
   P* v = a.v[t];
-  P pi = p[i];
+  P pi = e.p;
   const P gi = graw + k.pwd * pi;
   if (OPT == OPT_ADAM) {
-    const P mi = m[i] + (gi - m[i]) * k.omb1;
-    const P vi = v[i] * k.pb2 + gi * gi * k.omb2;
+    const P mi = e.m + (gi - e.m) * k.omb1;
+    const P vi = e.v * k.pb2 + gi * gi * k.omb2;
     pi -= k.c1 * (mi / (sqrt(vi) / k.bc2s + k.peps));
     m[i] = mi; v[i] = vi;
   } else if (OPT == OPT_RMSPROP) {
-    const P si = v[i] * k.pa + gi * gi * k.oma;
+    const P si = e.v * k.pa + gi * gi * k.oma;
     pi -= k.plr * (gi / (sqrt(si) + k.peps));
     v[i] = si;
   } else {
-    const P mi = m[i] * k.pb1 + gi * k.omb1;
-    const P vi = v[i] * k.pb2 + gi * gi * k.omb2;
+    const P mi = e.m * k.pb1 + gi * k.omb1;
+    const P vi = e.v * k.pb2 + gi * gi * k.omb2;
     const P denom = sqrt(vi) / k.bc2s + k.peps;
     pi -= k.c1 * (gi / denom);
     pi -= k.c2 * (mi / denom);
@@ -384,6 +395,10 @@ __device__ __forceinline__ void opt_update(const MultiArgs<P>& a, const OptConst
       if (a.flip[t]) a.flip[t][((long)ci * kk + (kk - 1 - j)) * a.pk_cout[t] + o] = (__bf16)(float)pi;
     }
   }
+}
+template <typename P, int OPT>
+__device__ __forceinline__ void opt_update(const MultiArgs<P>& a, const OptConst<P>& k, int t, long i, P graw) {
+  opt_apply<P, OPT>(a, k, t, i, graw, opt_load<P, OPT>(a, t, i));
 }
 
 // slab element q of a job -> (output of the job, element of that output); false: padding
@@ -499,10 +514,17 @@ __global__ __launch_bounds__(256) void multi_opt_kernel(const MultiArgs<P> args,
     const long base = (long)(bid - (t == 0 ? 0 : a.blk_end[t - 1])) * kChunk;
     const P* g = a.g[t];
     const int n = a.n[t];
+    OptElem<P> el[kChunk / 256];
+    P gr[kChunk / 256];
+#pragma unroll
+    for (int u = 0; u < kChunk / 256; ++u) {               // all loads first (see opt_load)
+      const long i = base + u * 256 + threadIdx.x;
+      if (i < n) { el[u] = opt_load<P, OPT>(a, t, i); gr[u] = g[i]; }
+    }
 #pragma unroll
     for (int u = 0; u < kChunk / 256; ++u) {
       const long i = base + u * 256 + threadIdx.x;
-      if (i < n) opt_update<P, OPT>(a, kc, t, i, g[i]);
+      if (i < n) opt_apply<P, OPT>(a, kc, t, i, gr[u], el[u]);
     }
     return;
   }
@@ -531,8 +553,10 @@ __global__ __launch_bounds__(256) void multi_opt_kernel(const MultiArgs<P> args,
 #pragma unroll
   for (int e = 0; e < 4; ++e) red[e][sl * qpb + qi] = acc[e];
   __syncthreads();
-  if (sl == 0 && q0 < per) {
-    for (int e = 0; e < sj.vec; ++e) {
+  // lane sl of the group updates element sl, sl + lanes, .. of the group's `vec` elements: with four or more lanes the elements
+  // of a group are updated side by side (one memory round trip, not `vec`)
+  if (q0 < per) {
+    for (int e = sl; e < sj.vec; e += lanes) {
       P sum = 0;
       for (int i = 0; i < lanes; ++i) sum += red[e][i * qpb + qi];
       int which;
