@@ -187,34 +187,43 @@ __device__ __forceinline__ void gram_job(int job, const GramPre& pre, const __bf
         }
       }
     }
-    // sixteen sums: within each row of 16 lanes by DPP (no LDS round trips), then the 4 * NWV row sums in row order
+    // sixteen sums: within each row of 16 lanes by DPP (no LDS round trips), across the four rows with two shuffles (the sixteen
+    // chains are independent), then the NWV wave sums in wave order
 #pragma unroll
     for (int e = 0; e < 16; ++e) {
-      const float r = row16_sum<float>(p[e]);
-      if ((lane & 15) == 0) scratch[e * (4 * NWV) + wave * 4 + (lane >> 4)] = r;
+      float r = row16_sum<float>(p[e]);
+      r += __shfl_xor(r, 16, 64);
+      r += __shfl_xor(r, 32, 64);
+      if (lane == 0) scratch[e * NWV + wave] = r;
     }
     __syncthreads();
     if (t < 16) {
       float s = 0.0f;
-      for (int w = 0; w < 4 * NWV; ++w) s += scratch[t * (4 * NWV) + w];
+#pragma unroll
+      for (int w = 0; w < NWV; ++w) s += scratch[t * NWV + w];
       if (prod) tot[kGramP + job * 16 + t] = s;
       else if ((t & 3) == 0) tot[kGramEdgeS + (job - NP) * 4 + (t >> 2)] = s;   // (sum slot c1 * 4: the edge value of channel c1)
     }
     __syncthreads();
     return;
   }
-  // G0: eight of the 4 x 64 compact entries; thread (row group rg, entry): rows rg, rg + G, .. of every part; the groups meet in
-  // group order; the totals keep the padded column index the finish uses (tap * 8 + c2; the ones column -> kGramOnesCol)
+  // G0: eight of the 4 x 64 compact entries; thread (row group rg, entry): rows rg, rg + G, .. of every part; the eight row groups
+  // of a wave meet by DPP / shuffles (lanes 8 apart hold the same entry), the waves in wave order; the totals keep the padded
+  // column index the finish uses (tap * 8 + c2; the ones column -> kGramOnesCol)
   constexpr int G = NTHR / 8;
   const int o = (job - NP - NE) * 8 + (t & 7), rg = t >> 3;
   float acc = 0.0f;
   for (int r = rg; r < rows; r += G)
     for (int h = 0; h < parts; ++h) acc += part[(long)r * kGramPart + h * 256 + o];
-  scratch[rg * 8 + (t & 7)] = acc;
+  acc += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, acc), 0x128, 0xf, 0xf, true));   // row_ror:8
+  acc += __shfl_xor(acc, 16, 64);
+  acc += __shfl_xor(acc, 32, 64);
+  if (lane < 8) scratch[wave * 8 + lane] = acc;
   __syncthreads();
   if (t < 8) {
     float s = 0.0f;
-    for (int q = 0; q < G; ++q) s += scratch[q * 8 + t];
+#pragma unroll
+    for (int q = 0; q < NWV; ++q) s += scratch[q * 8 + t];
     const int ci = o >> 6, np = o & 63;
     tot[kGramG0 + ci * 128 + (np == kGramOnesC ? kGramOnesCol : (np >> 2) * 8 + (np & 3))] = s;
   }
