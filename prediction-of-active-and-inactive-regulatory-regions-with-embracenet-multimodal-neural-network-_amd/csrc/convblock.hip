@@ -349,6 +349,14 @@ __device__ __forceinline__ void bn_bwd_dz_body(const T* __restrict__ dout, const
   const int NPmax = TT / 2 + 5;
   T* dsm = reinterpret_cast<T*>(smem);                                   // [NPmax][C]
   uint8_t* asm_ = reinterpret_cast<uint8_t*>(smem) + (size_t)NPmax * C * sizeof(T);   // [NPmax][C]
+  // this thread's first two activation rows are requested NOW: they arrive while the pooled gradient is staged (one memory
+  // round trip per item instead of two)
+  V yq0, yq1;
+  {
+    const int ta = t0 + ty, tb = t0 + ty + TY;
+    if (ty < TY && ta < t_end) yq0 = *reinterpret_cast<const V*>(y + ((long)b * L + ta) * C + c0);
+    if (ty < TY && tb < t_end) yq1 = *reinterpret_cast<const V*>(y + ((long)b * L + tb) * C + c0);
+  }
   if (NP > 0) {
     const long nlc0 = ((long)b * Lp + P0) * C;
     const int nvec = NP * C / VEC;
@@ -371,7 +379,8 @@ __device__ __forceinline__ void bn_bwd_dz_body(const T* __restrict__ dout, const
   }
   __syncthreads();
   if (ty < TY) {
-    for (int t = t0 + ty; t < t_end; t += TY) {
+    int jj = 0;
+    for (int t = t0 + ty; t < t_end; t += TY, ++jj) {
       Acc dz[VEC];
 #pragma unroll
       for (int e = 0; e < VEC; ++e) dz[e] = 0;
@@ -389,7 +398,10 @@ __device__ __forceinline__ void bn_bwd_dz_body(const T* __restrict__ dout, const
           if ((int)((am >> (8 * e)) & 0xFF) == off) dz[e] += (Acc)g[e] * (Acc)keep_scale;   // dropped: bit 7 set, never equal
       }
       const long r = (long)b * L + t;
-      const V yv = *reinterpret_cast<const V*>(y + r * C + c0);
+      V yv;
+      if (jj == 0) yv = yq0;
+      else if (jj == 1) yv = yq1;
+      else yv = *reinterpret_cast<const V*>(y + r * C + c0);
       V o;
 #pragma unroll
       for (int e = 0; e < VEC; ++e) {
