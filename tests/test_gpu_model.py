@@ -589,3 +589,45 @@ def test_kfold_cv_driver_runs_on_device_loaders(ea, tmp_path, monkeypatch):
     with pytest.raises(NotImplementedError):                     # a split the reference would re-balance: loud, not silent
         cv.rebalance_threshold = 0.45
         cv.build_dataloaders_forCV(X1, X2, y, 16, True, False)
+
+
+def test_parked_first_block_finish_falls_back_when_the_optimizer_lacks_its_tensors(ea):
+    """bf16 step runner: the first conv block's backward parks its per-channel finish for the optimizer launch
+    (csrc/first_fin.h).  An optimizer that does not hold the block's beta cannot take it over: the launch must then run the
+    finish the classic way first -- every parameter the optimizer does hold ends up exactly as in the all-parameters run
+    (Adam is element-wise), and the left-out one keeps its value while its .grad is still produced."""
+    from embracenet_amd import optim, training
+    def run(leave_out):
+        model, trial, hp, F_in = build(ea, "cfg1", "park", torch.float32)
+        model = training.prepare_model(model, DEV, "bfloat16").set_rng("philox", seed=9)
+        names = dict(model.named_parameters())
+        skip = [k for k in names if k.startswith("CNN.CNN_model.") and k.endswith(".bias") and "1." in k.split("CNN_model.")[1][:2]]
+        assert len(skip) == 1, skip                       # BatchNorm beta of block 1 (CNN_pre.py:37-44: conv, bn, relu, pool)
+        params = [p for k, p in names.items() if not (leave_out and k == skip[0])]
+        opt = optim.Adam(params, lr=1e-3, weight_decay=1e-3)
+        runner = training.StepRunner(model, opt, DEV)
+        table = ea.metrics.StepTable(2, DEV)
+        model.train()
+        before = names[skip[0]].detach().clone()
+        for k in range(1):
+            a, b, y = model_batch(f"park/{k}", 64, F_in, 0.3)
+            runner.train_step(torch.from_numpy(a).float(), torch.from_numpy(b).float(), torch.from_numpy(y), table)
+        torch.cuda.synchronize()
+        return ({k: v.detach().cpu().clone() for k, v in names.items()}, names[skip[0]].grad.detach().cpu().clone(),
+                before.cpu(), skip[0], table.fetch()[0].tolist())
+    pa, ga, _, name, la = run(False)
+    pb, gb, before, _, lb = run(True)
+    assert la[0] == lb[0]                                  # the step sees identical parameters
+    assert torch.equal(pb[name], before)                   # not in the optimizer: untouched
+    assert torch.isfinite(gb).all() and gb.abs().max() > 0 and torch.allclose(ga, gb, rtol=1e-5, atol=1e-7)
+    for k in pa:
+        if k == name:
+            continue
+        if k.startswith("CNN.CNN_model.0.") or k.startswith("CNN.CNN_model.1."):
+            # the standalone finish sums its slab with 1024 threads, the one inside the optimizer launch with 256: another order.
+            # The first Adam step moves every element by ~lr whatever the gradient's size, so an element whose gradient is
+            # rounding noise around zero may move the other way
+            assert (pa[k] - pb[k]).abs().max().item() <= 2.1e-3, k
+            assert ((pa[k] - pb[k]).abs() > 1e-6).float().mean().item() < 0.01, k
+        else:
+            assert torch.equal(pa[k], pb[k]), k
