@@ -12,7 +12,7 @@ conv = nn.Conv1d(4, 64, 15, padding=7).cuda(); bn = nn.BatchNorm1d(64).cuda()
 conv2 = nn.Conv1d(64, 32, 15, padding=7).cuda(); bn2 = nn.BatchNorm1d(32).cuda()
 layers = [dict(conv=conv, bn=bn, drop_p=0.0, layer_id=4), dict(conv=conv2, bn=bn2, drop_p=0.0, layer_id=5)]
 x = torch.rand(1024, 4, 256, device="cuda")
-for mode in (4,):
+for mode in (0, 1, 4):
     L.emb_debug_first_prof(buf, mode)
     for _ in range(5):
         y = F.conv_stack(x, layers, True, rng=F.RngState(seed=1), compute_dtype=torch.bfloat16)
