@@ -267,7 +267,10 @@ int64_t emb_convblock_stats_elems(int B, int L, int cin_pad, int Cout, int k, in
  * on == 0 switches it for the following emb_convblock_fwd + emb_convblock_bwd PAIRS (the backward needs what its forward left in
  * `stats`), on < 0 only asks.  Returns the previous setting.  In a deferring step (emb_reduce_defer) that backward parks its
  * per-channel finish until the optimizer launch (emb_*_step_multi holding the block's weight, gamma and beta gradients) or
- * emb_reduce_flush: `stats`, the workspace, `wpack` and `bias` of the call must stay valid and untouched until then. */
+ * emb_reduce_flush: `stats`, the workspace, `wpack` and `bias` of the call must stay valid and untouched until then.
+ * The forward likewise parks the jobs that write the lag-statistics totals into `stats`: the next emb_head_ce on the stream carries
+ * them; otherwise the block's emb_convblock_bwd, its next emb_convblock_fwd or emb_reduce_flush launch them.  `stats` and the
+ * workspace of the forward must therefore stay valid until one of those calls (they do in any forward -> backward sequence). */
 int emb_convblock_first_linear(int on);
 
 /* Slab reductions.  The weight-gradient kernels of emb_embrace_bwd / emb_linear_bwd / emb_mlp_bwd / emb_convblock_bwd write

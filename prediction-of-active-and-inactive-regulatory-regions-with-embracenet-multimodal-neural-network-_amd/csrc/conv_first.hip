@@ -969,6 +969,13 @@ int conv_first_apply(const void* x, int x_codes, const void* w, const void* bias
   if (fin != nullptr) a.fin_f = *fin;
   a.gram_part = const_cast<float*>(gram_part); a.gram_tot = gram_tot; a.gram_rows = gm.nblk;
   a.gram_edge = gram_part ? reinterpret_cast<__bf16*>(const_cast<float*>(gram_part) + (size_t)gm.nblk * kGramPart) : nullptr;
+  static const bool park = [] { const char* e = getenv("EMB_GRAM_PARK"); return !(e && e[0] == '0'); }();
+  if (gram_tot != nullptr && gram_part != nullptr && park) {   // the totals jobs leave this launch's prologue (first_fin.h)
+    GramJobsArgs j{};
+    j.edge = a.gram_edge; j.part = gram_part; j.tot = gram_tot; j.B = B; j.L = L; j.rows = gm.nblk; j.parts = Cout == 64 ? 2 : 1;
+    gram_jobs_park(j, s);
+    a.gram_tot = nullptr;
+  }
   return first_launch<F_APPLY>(a, gm, s);
 }
 
@@ -1046,6 +1053,20 @@ int first_fin_launch(const FirstFinArgs& f, hipStream_t s) {
   EMB_CHECK_LAUNCH();
   return EMB_OK;
 }
+
+// the totals jobs as a launch of their own (a parked set nobody carried) ...
+__global__ __launch_bounds__(256) void gram_jobs_kernel(const GramJobsArgs a) {
+  __shared__ float scratch[16 * 4];
+  GramPre pre;
+  pre.have = false;
+  gram_job<256>((int)blockIdx.x, pre, a.edge, a.B, a.L, a.part, a.rows, a.parts, a.tot, scratch);
+}
+int gram_jobs_launch(const GramJobsArgs& a, hipStream_t s) {
+  gram_jobs_kernel<<<kGramJobs, 256, 0, s>>>(a);
+  EMB_CHECK_LAUNCH();
+  return EMB_OK;
+}
+int gram_jobs_count() { return kGramJobs; }
 
 int conv_first_gram_floats() { return kGramRow; }
 size_t conv_first_gram_part_bytes(int B, int L, int cin_pad, int Cout, int k) {   // partial G0 rows, then the edge image

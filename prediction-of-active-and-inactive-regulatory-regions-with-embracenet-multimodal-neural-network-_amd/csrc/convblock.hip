@@ -14,6 +14,7 @@
 // pooled gradient by a deterministic gather (no atomics anywhere: results are bitwise reproducible).
 #include "conv_direct.h"
 #include "conv_first.h"
+#include "first_fin.h"
 #include "rider.h"
 #include "reduce.h"
 #include "gemm_tile.h"
@@ -722,6 +723,7 @@ static int convblock_fwd(const void* x, const void* wpack, const void* bias, con
                   "emb_convblock_fwd: y may only be NULL when emb_convblock_needs_y() returns 0");
     int rows = 0;
     if (training && bn_phase != 2) {
+      { const int rcj = gram_jobs_flush(s); if (rcj != EMB_OK) return rcj; }   // a set parked by the previous forward reads this workspace
       const int rc0 = conv_first_stats(x, x_codes, x_codes == 2 ? y : nullptr, wpack, bias, ws, &rows,
                                        first_linear<T>(training, bn_phase) ? (float*)((char*)ws + w.stat_partial) : nullptr, B, L, Cout, k, s);
       if (rc0 != EMB_OK) return rc0 == 1 ? EMB_ERR_ARG : rc0;
@@ -833,6 +835,8 @@ static int convblock_bwd(const void* dout, int dout_ncl, const uint8_t* argmax, 
                       (size_t)nb * Cout * 64 * sizeof(float) <= w.slab,
                   "emb_convblock_bwd: workspace layout too small for the fused first block");
     int rows = 0, S = 0, rc = EMB_OK;
+    rc = gram_jobs_flush(s);   // parked totals jobs nobody carried: they read the workspace the backward is about to reuse
+    if (rc != EMB_OK) return rc;
     if (first_linear<T>(training, bn_phase)) {   // one pass A = g^T xview + a per-channel finish: no convolution, no sums pass (first_gram.h)
       rc = conv_first_bwd_acc(dout, dout_ncl, argmax, x, x_codes, keep_scale, slab, &S, B, L, Cout, k, s);
       if (rc != EMB_OK) return rc == 1 ? EMB_ERR_ARG : rc;

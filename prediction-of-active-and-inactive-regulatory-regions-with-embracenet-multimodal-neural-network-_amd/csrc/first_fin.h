@@ -27,4 +27,20 @@ void first_fin_drop();                       // the optimizer launch took it ove
 int first_fin_flush(hipStream_t s);          // launches a parked job the classic way (emb_reduce_flush, or an optimizer call that cannot take it)
 int first_fin_launch(const FirstFinArgs& f, hipStream_t s);   // conv_first.hip
 
+// The totals of the lag statistics (first_gram.h, gram_job): kGramJobs independent jobs that only have to be done before the block's
+// backward.  The apply pass parks them instead of running them in its prologue; the head / loss launch of the same forward
+// (head.hip) carries them as extra workgroups on CUs it leaves idle.  Anything that would overwrite their inputs or needs their
+// output flushes a parked set as a launch of its own: the block's next forward, its backward, emb_reduce_flush.
+struct GramJobsArgs {
+  const __bf16* edge;       // edge image [112][B]
+  const float* part;        // [rows][512] partial G0 rows
+  float* tot;               // [4096] totals
+  int B, L, rows, parts;
+};
+void gram_jobs_park(const GramJobsArgs& a, hipStream_t s);    // (one slot: a set parked earlier is launched first)
+bool gram_jobs_take(GramJobsArgs* out);                       // a carrier launch takes the parked set over
+int gram_jobs_flush(hipStream_t s);
+int gram_jobs_launch(const GramJobsArgs& a, hipStream_t s);   // conv_first.hip
+int gram_jobs_count();                                        // kGramJobs
+
 }  // namespace emb

@@ -14,6 +14,7 @@
 // belongs to the logits the caller sees.
 #include "reduce.h"
 #include "conv_tiles.h"
+#include "first_gram.h"
 
 namespace emb {
 
@@ -34,6 +35,9 @@ struct HeadArgs {
   uint64_t* tick_a;
   uint64_t* tick_b;
   int B, K;
+  // parked totals jobs of the first conv block's lag statistics (first_fin.h): workgroups nblk .. nblk + njobs - 1 of the launch
+  GramJobsArgs jobs;
+  int nblk, njobs;
 };
 
 template <typename T> __device__ __forceinline__ void load4(const T* p, float (&v)[4]);
@@ -69,6 +73,13 @@ template <typename T, int KS> __global__ __launch_bounds__(256) void head_ce_ker
   extern __shared__ __attribute__((aligned(16))) float red[];   // [4 waves][2][KS*256] weight-gradient partials
   __shared__ long long scount[256];
   __shared__ float sstat[4][8];
+  if ((int)blockIdx.x >= a.nblk) {   // a carried job: this launch leaves most CUs idle
+    GramPre pre;
+    pre.have = false;
+    gram_job<256>((int)blockIdx.x - a.nblk, pre, a.jobs.edge, a.jobs.B, a.jobs.L, a.jobs.part, a.jobs.rows, a.jobs.parts, a.jobs.tot,
+                  reinterpret_cast<float*>(scount));
+    return;
+  }
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int B = a.B, K = a.K;
 
@@ -247,9 +258,11 @@ extern "C" int emb_head_ce(const void* E, const void* W, const void* bias, const
   a.slab = (float*)workspace;
   a.stats = a.slab + (long)nblk * 2 * (K + 1);
   a.tick_a = tick_a; a.tick_b = tick_b; a.B = B; a.K = K;
+  a.nblk = nblk;
+  a.njobs = gram_jobs_take(&a.jobs) ? gram_jobs_count() : 0;
   const size_t lds = (size_t)4 * 2 * KS * 256 * sizeof(float);
   hipStream_t s = (hipStream_t)stream;
-#define EMB_HEAD_LAUNCH(TT, KK) head_ce_kernel<TT, KK><<<nblk, 256, lds, s>>>(a)
+#define EMB_HEAD_LAUNCH(TT, KK) head_ce_kernel<TT, KK><<<nblk + a.njobs, 256, lds, s>>>(a)
   if (dtype == EMB_BF16) {
     switch (KS) {
       case 1: EMB_HEAD_LAUNCH(__bf16, 1); break;

@@ -195,6 +195,26 @@ bool first_fin_peek(FirstFinArgs* out) {
 }
 void first_fin_drop() { g_fin_valid = false; }
 
+// ---- the parked totals jobs of the first conv block's lag statistics (first_fin.h)
+static GramJobsArgs g_jobs;
+static bool g_jobs_valid = false;
+int gram_jobs_flush(hipStream_t s) {
+  if (!g_jobs_valid) return EMB_OK;
+  g_jobs_valid = false;
+  return gram_jobs_launch(g_jobs, s);
+}
+void gram_jobs_park(const GramJobsArgs& a, hipStream_t s) {
+  (void)gram_jobs_flush(s);
+  g_jobs = a;
+  g_jobs_valid = true;
+}
+bool gram_jobs_take(GramJobsArgs* out) {
+  if (!g_jobs_valid) return false;
+  *out = g_jobs;
+  g_jobs_valid = false;
+  return true;
+}
+
 int reduce_submit(const ReduceJob& job, bool is_double, hipStream_t s) {
   if (job.per <= 0 || job.S <= 0) return EMB_OK;
   if (g_defer) {
@@ -215,6 +235,8 @@ extern "C" int emb_reduce_defer(int on) {
 extern "C" int emb_reduce_flush(emb_stream_t stream) {
   emb::Pending& p = emb::pending();
   int rc = emb::rider_flush();   // a parked launch may be the producer of a queued slab
+  if (rc != EMB_OK) return rc;
+  rc = emb::gram_jobs_flush((hipStream_t)stream);
   if (rc != EMB_OK) return rc;
   rc = emb::first_fin_flush((hipStream_t)stream);
   if (rc != EMB_OK) return rc;

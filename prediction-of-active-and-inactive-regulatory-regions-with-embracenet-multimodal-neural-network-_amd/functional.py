@@ -335,6 +335,8 @@ def _parr(tensors):
 
 
 _RIDER_KEEP = []     # tensors a parked rider launch reads or writes: kept alive until the flush
+_JOBS_KEEP = []      # the same tensor from the forward on: the totals of the lag statistics are written into it by jobs that the head
+                     # launch carries (csrc/first_fin.h), or that the block's next forward / its backward flush
 _FIN_KEEP = []       # BatchNorm vectors + lag statistics of the first conv block: its backward's finish may be parked until the
                      # optimizer launch (csrc/first_fin.h) and reads them there; released when the next backward parks its own
 
@@ -735,6 +737,8 @@ class _ConvStackFn(torch.autograd.Function):
                       "emb_convblock_fwd")
                 if phase == 1:
                     sync(sums)                                       # {sum y, sum y^2, rows} of the shard -> of the global batch
+            if fused:
+                _JOBS_KEEP[:] = [stats]
             saved += [cur, y if y is not None else stats, stats, argmax, wflip if wflip is not None else stats, wpack, b.detach()]
             shapes.append((L, Cin, cin_pad, Cout, k, float(m["drop_p"]), fused))
             cur, L, cin_pad = out, Lp, Cout
