@@ -71,9 +71,9 @@ struct FirstArgs {
   float drop_p, keep_scale;
   int ncl, training, layer_id;
   int B, L, Lp, KK, C, pad, SB, slot, tiles_m, tpb;
-  // Lag statistics of the INPUT (first_gram.h): F_STATS writes one partial row of kGramRow floats per workgroup to `gram_part`
-  // (nullptr: not wanted); F_APPLY's prologue sums the `gram_rows` partial rows column-wise (each workgroup a few columns) into
-  // `gram_tot`, which the recompute-free backward (first_bwd_finish_kernel) reads.
+  // Lag statistics of the INPUT (first_gram.h): F_STATS writes one partial G0 row (kGramPart floats) per workgroup to `gram_part`
+  // (nullptr: not wanted) and the edge image; the totals jobs (gram_job: parked for the head launch, or -- gram_tot != nullptr --
+  // run in F_APPLY's prologue, one per workgroup) turn them into `gram_tot`, which the recompute-free backward's finish reads.
   float* gram_part;
   float* gram_tot;
   __bf16* gram_edge;        // the edge image (first_gram.h): F_STATS writes it, F_APPLY's jobs read it

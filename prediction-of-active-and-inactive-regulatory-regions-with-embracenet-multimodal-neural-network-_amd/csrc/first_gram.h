@@ -27,12 +27,12 @@
 
 namespace emb {
 
-// layout of a partial / total row (floats)
+// layout of the TOTALS row (floats)
 constexpr int kGramG0 = 0;                       // [4][128]        G0[ci][tap * 8 + c2]
 constexpr int kGramP = 512;                      // [2][7][15][16]  P(u, d) at the head (which = 0: position u) / tail (position L - 1 - u)
-constexpr int kGramColS = kGramP + 2 * 7 * 15 * 16;   // [8][4]     column sums of x, 8 chunks of 32 positions
-constexpr int kGramEdgeS = kGramColS + 64;       // [2][7][4]       x at the head / tail positions
-constexpr int kGramRow = 4096;                   // floats per row (3992 used)
+constexpr int kGramColS = kGramP + 2 * 7 * 15 * 16;   // (64 floats not in use)
+constexpr int kGramEdgeS = kGramColS + 64;       // [2][7][4]       x at the head / tail positions, summed over the batch
+constexpr int kGramRow = 4096;                   // floats per totals row (3992 used)
 constexpr int kGramMaxK = 15, kGramEdge = 7;     // taps, edge positions (k <= 15)
 constexpr int kGramOnesCol = 120;                // column of G0 that holds sum_r x~[r - pad][ci] = colTot - TailS[pad] (k * 8 <= 120)
 
@@ -40,7 +40,7 @@ constexpr int kGramEdgeHead = 21, kGramEdgeTail = 7, kGramEdgeRows = (kGramEdgeH
 constexpr int kGramPart = 512;                    // floats per PARTIAL row (one per statistics workgroup): the G0 block only
 constexpr int kGramJobs = 2 * kGramEdge * kGramMaxK + 2 * kGramEdge + kGramPart / 16;   // 210 edge products, 14 edge sums, 32 G0 column blocks
 
-// one tile of the statistics pass.  xs: the staged tile [rows][8] bf16 (zero halos), row_off(row): LDS element offset of tile row `row`.
+// one tile of the statistics pass.  xs: the staged tile [rows][8] bf16 (zero halos, channels 4..7 zero), row_off(row): LDS element offset of tile row `row`.
 // G0 on the matrix cores over the REAL channels: A = x~[r - pad] (the tap-0 block of the view), B = compact 16-column block nb of
 // the view (column n' = tap * 4 + c2: a lane's transposing read takes the four real channels of tap nb * 4 + p4), 64 columns =
 // four blocks.  Wave = (block nb, part kh of the k-steps): NW / 4 partial accumulators per block, stored side by side.
