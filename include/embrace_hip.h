@@ -98,6 +98,40 @@ int emb_embrace_bwd(const void* dE, const uint8_t* code, const void* X0, const v
                     void* workspace, int64_t workspace_bytes, int B, int d0, int d1, int c, int dtype,
                     emb_stream_t stream);
 
+/* EmbraceNet with bypass_docking=True (EmbraceNetMultimodal.py:20 "connect the input data directly to the embracement
+ * layer", :54-55): the inputs are the docking outputs, the layer is the selection alone -- :63-76 (availability *
+ * probability, renormalise), :80 (stack), :84 (multinomial), :85 (one_hot), :87-88 (mul, sum).  One elementwise launch.
+ *   X0, X1 [B,c] T;  E [B,c] T out;  code [B,c] u8 out (IDX bit 0; ACTIVE always set: there is no ReLU on this path)
+ *   thresholds: cdf0 [B] fp32 from emb_select_prep, or cdf0 == NULL and (p, p_rows, avail, device_dropout, status) with
+ *   the meaning and arithmetic of emb_embrace_fwd_select;  u [B,c] fp64 or NULL -> Philox kind 0 (same RNG contract). */
+int emb_embrace_bypass_fwd(const void* X0, const void* X1, const float* cdf0, const float* p, int p_rows,
+                           const float* avail, int device_dropout, int32_t* status, const double* u, uint64_t seed,
+                           uint64_t step_val, const uint64_t* step_dev, int64_t row0, void* E, uint8_t* code, int B, int c,
+                           int dtype, emb_stream_t stream);
+/* autograd of the above: dX_m = dE * [idx == m];  dX0, dX1 [B,c] T, either may be NULL (not needed). */
+int emb_embrace_bypass_bwd(const void* dE, const uint8_t* code, void* dX0, void* dX1, int B, int c, int dtype,
+                           emb_stream_t stream);
+
+/* EmbraceNet.forward for any number of modalities M (1 <= M <= 8; EmbraceNetMultimodal.py:46-48 takes len(input_list)):
+ * the docking layers (:52-60) are M calls of emb_linear_fwd with relu != 0, the rest of the layer is the three entries below.
+ * (The reference's own call sites use M == 2, which emb_embrace_fwd fuses into one launch.)
+ *
+ * emb_select_prep_m -- :63-76 and the cdf torch.multinomial builds (:84), as emb_select_prep for M columns:
+ *   p [p_rows, M] fp32 (p_rows == 1 or B), avail [B, M] fp32 or NULL, cdf [B, M] fp32 out (NaN row + status bit when invalid)
+ * emb_embrace_select_fwd -- :80 (stack), :84 (multinomial), :85 (one_hot), :87-88 (mul, sum):
+ *   D     host array of M device pointers, D[m] = docking output of modality m, [B,c] T
+ *   idx   = number of cdf entries m < M-1 with (double)cdf[row][m] < u  (ATen's binary search);  u, seed, step, row0: as
+ *           emb_embrace_fwd (u [B,c] fp64 or NULL -> Philox kind 0)
+ *   E [B,c] T out;  code [B,c] u8 out = idx (NOT the EMB_CODE_* bits of the two-modality kernels)
+ * emb_embrace_select_bwd -- autograd of the above: dD[m] = dE * [idx == m];  dD host array of M device pointers (NULL: skip) */
+int emb_select_prep_m(const float* p, int p_rows, const float* avail, float* cdf, int32_t* status, int B, int M,
+                      emb_stream_t stream);
+int emb_embrace_select_fwd(const void* const* D, int M, const float* cdf, const double* u, uint64_t seed,
+                           uint64_t step_val, const uint64_t* step_dev, int64_t row0, void* E, uint8_t* code, int B, int c,
+                           int dtype, emb_stream_t stream);
+int emb_embrace_select_bwd(const void* dE, const uint8_t* code, void* const* dD, int M, int B, int c, int dtype,
+                           emb_stream_t stream);
+
 /* One layer of the post stack, EmbraceNetMultimodal.py:143-147 / :151 (also FFNN_pre.py:25-33):
  * Y = dropout(relu(X W^T + b)).   X [B,K] T, W [N,K] T, b [N] P, Y [B,N] T.
  *   relu != 0 applies ReLU; dropout_p > 0 applies an inverted-dropout mask from RNG kind 16+layer_id.

@@ -112,6 +112,20 @@ def embrace_backward(dE, X, W, Z, idx):
     return dX, dW, db
 
 
+def embrace_bypass_forward(X, idx):
+    """EmbraceNetMultimodal.py:54-55 (bypass_docking: docking_output_list = input_list), :80-88 (stack, one-hot, mul, sum).
+    X[m] [B, c], idx [B, c]  ->  E [B, c] = X[idx[b, j]][b, j]."""
+    E = np.zeros_like(np.asarray(X[0]))
+    for m, x in enumerate(X):
+        E = np.where(idx == m, x, E)
+    return E
+
+
+def embrace_bypass_backward(dE, idx, M=2):
+    """Autograd of the above: dX_m = dE * one_hot(idx)[..., m]."""
+    return [dE * (idx == m) for m in range(M)]
+
+
 # --------------------------------------------------------------------------- a10
 def linear_forward(x, w, b, relu):
     """nn.Linear (+ nn.ReLU) of the post stack, EmbraceNetMultimodal.py:143-151."""

@@ -32,6 +32,11 @@ SIGNATURES = {
     "emb_embrace_fwd": [_vp] * 8 + [_u64, _u64, _vp, _i64, _vp, _vp, _i, _i, _i, _i, _i, _vp],
     "emb_embrace_fwd_select": [_vp] * 7 + [_i, _vp, _i, _vp, _vp, _u64, _u64, _vp, _i64, _vp, _vp, _i, _i, _i, _i, _i, _vp],
     "emb_embrace_bwd": [_vp] * 12 + [_vp, _i64, _i, _i, _i, _i, _i, _vp],
+    "emb_embrace_bypass_fwd": [_vp] * 4 + [_i, _vp, _i, _vp, _vp, _u64, _u64, _vp, _i64, _vp, _vp, _i, _i, _i, _vp],
+    "emb_embrace_bypass_bwd": [_vp] * 4 + [_i, _i, _i, _vp],
+    "emb_select_prep_m": [_vp, _i, _vp, _vp, _vp, _i, _i, _vp],
+    "emb_embrace_select_fwd": [_vp, _i, _vp, _vp, _u64, _u64, _vp, _i64, _vp, _vp, _i, _i, _i, _vp],
+    "emb_embrace_select_bwd": [_vp, _vp, _vp, _i, _i, _i, _i, _vp],
     "emb_linear_fwd": [_vp] * 5 + [_i, _f, _i, _u64, _u64, _vp, _i64, _i, _i, _i, _i, _vp],
     "emb_linear_bwd": [_vp] * 7 + [_i, _f, _vp, _i64, _i, _i, _i, _i, _vp],
     "emb_weighted_ce": [_vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _vp, _i, _i, _vp],

@@ -112,13 +112,16 @@ class EmbraceNet(nn.Module, _RngMixin):
                 _advance=True, _prep=None):
         assert len(input_list) == len(self.input_size_list)
         if len(input_list) != 2:
-            raise NotImplementedError("the gfx950 kernels implement the two-modality EmbraceNet")
-        if self.bypass_docking:
-            raise NotImplementedError("bypass_docking is not part of the accelerated path")
+            return self._forward_m(list(input_list), availabilities, selection_probabilities, _device_dropout, _advance)
         x0, x1 = input_list
         B, c = x0.shape[0], self.embracement_size
         dev = x0.device
-        T = self.compute_dtype or self.docking_0.weight.dtype
+        if self.bypass_docking:                                   # :54-55: the inputs are the docking outputs
+            if tuple(x0.shape) != (B, c) or tuple(x1.shape) != (B, c):
+                raise ValueError("bypass_docking: input data must have a shape of [batch_size, embracement_size]")
+            T = self.compute_dtype or x0.dtype
+        else:
+            T = self.compute_dtype or self.docking_0.weight.dtype
         rng = self._rng_state(dev)
         check = self.check_distribution if self.check_distribution is not None else (self.rng_mode == "host")
         if _prep is None and self.rng_mode == "philox" and not check:
@@ -136,15 +139,61 @@ class EmbraceNet(nn.Module, _RngMixin):
             raise RuntimeError("invalid multinomial distribution (encountering probability entry < 0)")
         self.last_status = status
 
-        E, code = F_.embrace(x0, x1, self.docking_0.weight, self.docking_0.bias, self.docking_1.weight,
-                             self.docking_1.bias, cdf0, u=u, rng=rng, compute_dtype=T)
+        if self.bypass_docking:
+            E, code = F_.embrace_bypass(x0, x1, cdf0, u=u, rng=rng, compute_dtype=T)
+        else:
+            E, code = F_.embrace(x0, x1, self.docking_0.weight, self.docking_0.bias, self.docking_1.weight,
+                                 self.docking_1.bias, cdf0, u=u, rng=rng, compute_dtype=T)
         self.last_code = code
+        self._code_is_index = False
+        if _advance:
+            self._advance_step()
+        return E
+
+    def _forward_m(self, xs, availabilities, selection_probabilities, _device_dropout, _advance):
+        """len(input_list) != 2 (:46-48; no call site of the reference): docking layers as M Linear+ReLU launches (:52-60),
+        then the selection pass over their outputs (:63-88)."""
+        M, c = len(xs), self.embracement_size
+        if not 1 <= M <= 8:
+            raise NotImplementedError("the selection kernels take 1..8 modalities")
+        if _device_dropout:
+            raise NotImplementedError("device-side modality dropout is the two-modality model's (:178-182)")
+        B, dev = xs[0].shape[0], xs[0].device
+        rng = self._rng_state(dev)
+        if self.bypass_docking:                                   # :54-55
+            if any(tuple(x.shape) != (B, c) for x in xs):
+                raise ValueError("bypass_docking: input data must have a shape of [batch_size, embracement_size]")
+            T = self.compute_dtype or xs[0].dtype
+            D = xs
+        else:
+            T = self.compute_dtype or self.docking_0.weight.dtype
+            D = [F_.linear(x, getattr(self, "docking_%d" % m).weight, getattr(self, "docking_%d" % m).bias, relu=True,
+                           rng=rng, compute_dtype=T) for m, x in enumerate(xs)]
+        p = selection_probabilities
+        p = torch.ones(1, M, dtype=torch.float32, device=dev) if p is None else p.to(device=dev, dtype=torch.float32)   # :70-71
+        avail = None if availabilities is None else availabilities.to(device=dev, dtype=torch.float32)
+        if getattr(self, "_status", None) is None or self._status.device != dev:
+            self._status = torch.zeros(1, dtype=torch.int32, device=dev)
+        cdf, status = F_.select_prep_m(p, avail, B, M, status=self._status)
+        u = None
+        if self.rng_mode == "host":                               # replay of torch.multinomial's draws (:84)
+            u = torch.rand(B * c, dtype=torch.float64, generator=self.generator).view(B, c).to(dev, non_blocking=True)
+        check = self.check_distribution if self.check_distribution is not None else (self.rng_mode == "host")
+        if check and int(status.item()) & STATUS_INVALID_DISTRIBUTION:
+            status.zero_()
+            raise RuntimeError("invalid multinomial distribution (encountering probability entry < 0)")
+        self.last_status = status
+        E, code = F_.embrace_select(D, cdf, u=u, rng=rng, compute_dtype=T)
+        self.last_code = code
+        self._code_is_index = True
         if _advance:
             self._advance_step()
         return E
 
     def modality_indices(self):
         """[B, c] int64 index tensor of the latest forward (what torch.multinomial returned in the reference)."""
+        if getattr(self, "_code_is_index", False):                # M != 2: the code byte is the index itself
+            return self.last_code.to(torch.int64)
         return (self.last_code & 1).to(torch.int64)
 
 

@@ -279,6 +279,122 @@ def embrace(x0, x1, w0, b0, w1, b1, cdf0, u=None, rng=None, compute_dtype=None):
     return _EmbraceFn.apply(x0, x1, w0, b0, w1, b1, cdf0, u, rng or RngState(), compute_dtype)
 
 
+class _EmbraceBypassFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x0, x1, cdf0, u, rng, compute_dtype):
+        _lib.require_cuda(x0, x1)
+        T = compute_dtype
+        if x0.shape != x1.shape or x0.dim() != 2:
+            raise ValueError("bypass_docking: both inputs must be [batch_size, embracement_size]")
+        B, c = x0.shape
+        x0c, x1c = _as(x0, T), _as(x1, T)
+        E = torch.empty(B, c, dtype=T, device=x0.device)
+        code = torch.empty(B, c, dtype=torch.uint8, device=x0.device)
+        if u is not None:
+            u = _as(u, torch.float64)
+            assert u.shape == (B, c)
+        if isinstance(cdf0, SelectInline):
+            s_ = cdf0
+            args = (None, ptr(s_.p), s_.p.shape[0], ptr(s_.avail), int(s_.device_dropout), ptr(s_.status))
+        else:
+            args = (ptr(cdf0), None, 0, None, 0, None)
+        check(_lib.lib().emb_embrace_bypass_fwd(ptr(x0c), ptr(x1c), *args, ptr(u), rng.seed, rng.step_val, ptr(rng.step_dev),
+                                                rng.row0, ptr(E), ptr(code), B, c, DTYPE_CODE[T], stream()),
+              "emb_embrace_bypass_fwd")
+        ctx.save_for_backward(code)
+        ctx.T, ctx.in_dtypes = T, (x0.dtype, x1.dtype)
+        ctx.mark_non_differentiable(code)
+        ctx.set_materialize_grads(False)
+        return E, code
+
+    @staticmethod
+    def backward(ctx, dE, _dcode):
+        if dE is None:
+            return (None,) * 6
+        code, = ctx.saved_tensors
+        T = ctx.T
+        B, c = code.shape
+        dE = _as(dE, T)
+        dX0 = torch.empty(B, c, dtype=T, device=code.device) if ctx.needs_input_grad[0] else None
+        dX1 = torch.empty(B, c, dtype=T, device=code.device) if ctx.needs_input_grad[1] else None
+        check(_lib.lib().emb_embrace_bypass_bwd(ptr(dE), ptr(code), ptr(dX0), ptr(dX1), B, c, DTYPE_CODE[T], stream()),
+              "emb_embrace_bypass_bwd")
+        cast = lambda g, d: None if g is None else (g if g.dtype == d else g.to(d))
+        return cast(dX0, ctx.in_dtypes[0]), cast(dX1, ctx.in_dtypes[1]), None, None, None, None
+
+
+def embrace_bypass(x0, x1, cdf0, u=None, rng=None, compute_dtype=None):
+    """Modality selection over ready-made docking outputs (EmbraceNet(bypass_docking=True), EmbraceNetMultimodal.py:54-55,
+    63-88): E[b, j] = x_{idx[b, j]}[b, j].  Arguments and return value as `embrace` without the docking parameters."""
+    return _EmbraceBypassFn.apply(x0, x1, cdf0, u, rng or RngState(), compute_dtype or x0.dtype)
+
+
+def select_prep_m(p, avail, B, M, status=None):
+    """EmbraceNetMultimodal.py:63-76 + torch.multinomial's cdf for M modalities -> cdf [B, M] (fp32, device)."""
+    _lib.require_cuda(p, avail)
+    p = _as(p, torch.float32)
+    p = p.view(1, -1) if p.dim() == 1 else p
+    if p.shape[-1] != M or p.shape[0] not in (1, B):
+        raise ValueError("selection_probabilities must be [B, M] or [M]")
+    if avail is not None:
+        avail = _as(avail, torch.float32)
+        if tuple(avail.shape) != (B, M):
+            raise ValueError("availabilities must be [B, M]")
+    cdf = torch.empty(B, M, dtype=torch.float32, device=p.device)
+    if status is None:
+        status = torch.zeros(1, dtype=torch.int32, device=p.device)
+    check(_lib.lib().emb_select_prep_m(ptr(p), p.shape[0], ptr(avail), ptr(cdf), ptr(status), B, M, stream()),
+          "emb_select_prep_m")
+    return cdf, status
+
+
+class _EmbraceSelectFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, cdf, u, rng, compute_dtype, *xs):
+        _lib.require_cuda(cdf, *xs)
+        T, M = compute_dtype, len(xs)
+        B, c = xs[0].shape
+        if any(tuple(x.shape) != (B, c) for x in xs) or tuple(cdf.shape) != (B, M):
+            raise ValueError("embrace_select: M inputs of [batch_size, embracement_size] and a cdf of [batch_size, M]")
+        xc = [_as(x, T) for x in xs]
+        E = torch.empty(B, c, dtype=T, device=xs[0].device)
+        code = torch.empty(B, c, dtype=torch.uint8, device=xs[0].device)
+        if u is not None:
+            u = _as(u, torch.float64)
+            assert u.shape == (B, c)
+        D = (_ct.c_void_p * M)(*[ptr(x) for x in xc])
+        check(_lib.lib().emb_embrace_select_fwd(D, M, ptr(_as(cdf, torch.float32)), ptr(u), rng.seed, rng.step_val,
+                                                ptr(rng.step_dev), rng.row0, ptr(E), ptr(code), B, c, DTYPE_CODE[T], stream()),
+              "emb_embrace_select_fwd")
+        ctx.save_for_backward(code)
+        ctx.T, ctx.in_dtypes = T, tuple(x.dtype for x in xs)
+        ctx.mark_non_differentiable(code)
+        ctx.set_materialize_grads(False)
+        return E, code
+
+    @staticmethod
+    def backward(ctx, dE, _dcode):
+        M = len(ctx.in_dtypes)
+        if dE is None:
+            return (None,) * (4 + M)
+        code, = ctx.saved_tensors
+        T = ctx.T
+        B, c = code.shape
+        dE = _as(dE, T)
+        dD = [torch.empty(B, c, dtype=T, device=code.device) if ctx.needs_input_grad[4 + m] else None for m in range(M)]
+        P = (_ct.c_void_p * M)(*[ptr(d) for d in dD])
+        check(_lib.lib().emb_embrace_select_bwd(ptr(dE), ptr(code), P, M, B, c, DTYPE_CODE[T], stream()),
+              "emb_embrace_select_bwd")
+        cast = lambda g, d: None if g is None else (g if g.dtype == d else g.to(d))
+        return (None, None, None, None) + tuple(cast(g, d) for g, d in zip(dD, ctx.in_dtypes))
+
+
+def embrace_select(xs, cdf, u=None, rng=None, compute_dtype=None):
+    """Modality selection over M docking outputs (EmbraceNetMultimodal.py:80-88): E[b, j] = xs[idx[b, j]][b, j] with
+    idx drawn from the rows of `cdf` ([B, M], from `select_prep_m`).  returns (E [B,c], idx [B,c] uint8)."""
+    return _EmbraceSelectFn.apply(cdf, u, rng or RngState(), compute_dtype or xs[0].dtype, *xs)
+
+
 class _LinearFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, w, b, relu, dropout_p, layer_id, rng, compute_dtype):

@@ -546,7 +546,138 @@ def g11():
     save("G11_balanced_batches", arrays, meta)
 
 
+# =========================================================================== G12
+def g12():
+    """EmbraceNet(bypass_docking=True) of the imported reference (EmbraceNetMultimodal.py:54-55): forward and the input
+    gradients of sum(out * dout)."""
+    arrays, meta = {}, {"cases": []}
+    for (B, c) in [(8, 32), (64, 512), (37, 767), (130, 1024)]:
+        for dt_name, dt in (("f64", torch.float64), ("f32", torch.float32)):
+            for av_kind, p_kind in (("none", "none"), ("mixed", "given"), ("none", "given")):
+                case = f"g12/B{B}_c{c}"
+                tag = f"{case}/{dt_name}/{av_kind}/{p_kind}"
+                seed = 5000 + len(meta["cases"])
+                X = [dg.uniform(case + "/x0", (B, c), -1, 1), dg.uniform(case + "/x1", (B, c), -1, 1)]
+                dout = dg.uniform(case + "/dout", (B, c), -1, 1)
+                avail = avail_variant(av_kind, case, B)
+                p = None if p_kind == "none" else dg.uniform(case + "/p", (B, 2), 0.05, 1.0).astype(np.float32)
+                net = EmbraceNet("cpu", [c, c], c, bypass_docking=True)
+                assert len(list(net.parameters())) == 0
+                xs = [torch.from_numpy(x).to(dt).requires_grad_(True) for x in X]
+                torch.manual_seed(seed)
+                out = net(xs, availabilities=None if avail is None else torch.from_numpy(avail),
+                          selection_probabilities=None if p is None else torch.from_numpy(p))
+                (out * torch.from_numpy(dout).to(dt)).sum().backward()
+                torch.manual_seed(seed)
+                u = torch.rand(B * c, dtype=torch.float64).view(B, c).numpy()
+                cdf = orc.selection_cdf(np.ones((B, 2), np.float32) if p is None else p, avail)
+                idx = orc.embrace_indices(cdf, u)
+                npdt = np.float64 if dt_name == "f64" else np.float32
+                Xc = [x.astype(npdt).astype(np.float64) for x in X]
+                E = orc.embrace_bypass_forward(Xc, idx)
+                dX = orc.embrace_bypass_backward(dout.astype(npdt).astype(np.float64), idx)
+                ref = out.detach().double().numpy()
+                assert np.array_equal(E, ref), tag                      # a select: exact
+                for m in range(2):
+                    assert np.array_equal(dX[m], xs[m].grad.double().numpy()), (tag, m)
+                key = tag.replace("/", "_")
+                arrays[key + "_idx"] = packbits(idx)
+                meta["cases"].append(dict(tag=tag, key=key, case=case, B=B, c=c, dtype=dt_name, avail=av_kind, p=p_kind,
+                                          seed=seed, out_chk=dg.checksum(ref), dx0_chk=dg.checksum(xs[0].grad.double().numpy()),
+                                          dx1_chk=dg.checksum(xs[1].grad.double().numpy()), idx_ones=int(idx.sum())))
+                print("G12", tag, "ones", int(idx.sum()))
+    save("G12_bypass_docking", arrays, meta)
+
+
+# =========================================================================== G13
+def g13_inputs(case):
+    name, B, ds, c, bypass = case["case"], case["B"], case["ds"], case["c"], case["bypass"]
+    M = len(ds)
+    X = [dg.uniform(f"{name}/x{m}", (B, d), -1, 1) for m, d in enumerate(ds)]
+    W = [] if bypass else [dg.weight(f"{name}/w{m}", (c, d), d) for m, d in enumerate(ds)]
+    b = [] if bypass else [dg.weight(f"{name}/b{m}", (c,), d) for m, d in enumerate(ds)]
+    dout = dg.uniform(name + "/dout", (B, c), -1, 1)
+    avail = None
+    if case["avail"] == "mixed":
+        a = dg.integers(name + "/avail", (B, M), 2).astype(np.float32)
+        a[np.arange(B), dg.integers(name + "/avail_keep", (B,), M)] = 1.0       # at least one modality per row
+        avail = a
+    p = None if case["p"] == "none" else dg.uniform(name + "/p", (B, M), 0.05, 1.0).astype(np.float32)
+    return X, W, b, dout, avail, p
+
+
+def g13():
+    """EmbraceNet of the imported reference with M != 2 modalities (EmbraceNetMultimodal.py:46-48), with and without
+    docking layers: indices, outputs, gradients of sum(out * dout)."""
+    arrays, meta = {}, {"cases": []}
+    shapes = [(16, [8, 12, 20], 32, False), (64, [16, 64, 256, 100], 512, False), (37, [5], 30, False),
+              (37, [30, 30, 30], 30, True), (33, [64] * 8, 64, True)]
+    for (B, ds, c, bypass) in shapes:
+        for dt_name, dt in (("f64", torch.float64), ("f32", torch.float32)):
+            for av_kind, p_kind in (("none", "none"), ("mixed", "given"), ("none", "given")):
+                M = len(ds)
+                case = dict(case=f"g13/B{B}_M{M}_c{c}_{int(bypass)}", B=B, ds=ds, c=c, bypass=bypass, avail=av_kind, p=p_kind)
+                tag = f"{case['case']}/{dt_name}/{av_kind}/{p_kind}"
+                seed = 7000 + len(meta["cases"])
+                X, W, b, dout, avail, p = g13_inputs(case)
+                net = EmbraceNet("cpu", ds, c, bypass_docking=bypass).to(dt)
+                if not bypass:
+                    with torch.no_grad():
+                        for m in range(M):
+                            getattr(net, f"docking_{m}").weight.copy_(torch.from_numpy(W[m]).to(dt))
+                            getattr(net, f"docking_{m}").bias.copy_(torch.from_numpy(b[m]).to(dt))
+                xs = [torch.from_numpy(x).to(dt).requires_grad_(True) for x in X]
+                torch.manual_seed(seed)
+                out = net(xs, availabilities=None if avail is None else torch.from_numpy(avail),
+                          selection_probabilities=None if p is None else torch.from_numpy(p))
+                (out * torch.from_numpy(dout).to(dt)).sum().backward()
+                torch.manual_seed(seed)
+                u = torch.rand(B * c, dtype=torch.float64).view(B, c).numpy()
+                cdf = orc.selection_cdf(np.ones((B, M), np.float32) if p is None else p, avail)
+                idx = orc.embrace_indices(cdf, u)
+                npdt = np.float64 if dt_name == "f64" else np.float32
+                Xc = [x.astype(npdt).astype(np.float64) for x in X]
+                dE = dout.astype(npdt).astype(np.float64)
+                ref = out.detach().double().numpy()
+                tol = 1e-12 if dt_name == "f64" else 2e-5
+                if bypass:
+                    E = orc.embrace_bypass_forward(Xc, idx)
+                    dX = orc.embrace_bypass_backward(dE, idx, M)
+                    assert np.array_equal(E, ref), tag
+                    D = Xc
+                else:
+                    Wc = [w.astype(npdt).astype(np.float64) for w in W]
+                    bc = [v.astype(npdt).astype(np.float64) for v in b]
+                    E, Z = orc.embrace_forward(Xc, Wc, bc, idx)
+                    dX, dW, db = orc.embrace_backward(dE, Xc, Wc, Z, idx)
+                    assert np.abs(E - ref).max() < tol, (tag, np.abs(E - ref).max())
+                    D = [np.maximum(z, 0) for z in Z]
+                    for m in range(M):
+                        lin = getattr(net, f"docking_{m}")
+                        assert np.abs(dW[m] - lin.weight.grad.double().numpy()).max() < tol * 10, (tag, m)
+                        assert np.abs(db[m] - lin.bias.grad.double().numpy()).max() < tol * 10, (tag, m)
+                for m in range(M):
+                    assert np.abs(dX[m] - xs[m].grad.double().numpy()).max() < tol * 10, (tag, m)
+                # the reference never returns idx: wherever the outputs tell the modalities apart it must be the oracle's
+                pick = np.stack([np.abs(ref - d) for d in D], -1)
+                ref_idx = pick.argmin(-1)
+                srt = np.sort(pick, -1)
+                amb = (srt[..., 1] - srt[..., 0] < 1e-6) if M > 1 else np.zeros_like(idx, bool)
+                assert np.all((ref_idx == idx) | amb), tag
+                key = tag.replace("/", "_")
+                arrays[key + "_idx"] = idx.astype(np.uint8)
+                arrays[key + "_out"] = ref.astype(np.float32) if B * c > 4096 else ref
+                cm = dict(case, tag=tag, key=key, dtype=dt_name, seed=seed, out_chk=dg.checksum(ref),
+                          dx_chk=[dg.checksum(x.grad.double().numpy()) for x in xs], hist=np.bincount(idx.ravel(), minlength=M).tolist())
+                if not bypass:
+                    cm["dw_chk"] = [dg.checksum(getattr(net, f"docking_{m}").weight.grad.double().numpy()) for m in range(M)]
+                    cm["db_chk"] = [dg.checksum(getattr(net, f"docking_{m}").bias.grad.double().numpy()) for m in range(M)]
+                meta["cases"].append(cm)
+                print("G13", tag, "hist", cm["hist"])
+    save("G13_m_modalities", arrays, meta)
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g5", "g6", "g7", "g8", "g9", "g10", "g11"]
+    which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g5", "g6", "g7", "g8", "g9", "g10", "g11", "g12", "g13"]
     for w in which:
         globals()[w]()

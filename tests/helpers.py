@@ -38,6 +38,35 @@ def g1_inputs(case):
     return X, W, b, avail, p
 
 
+def g12_inputs(case):
+    """Inputs of a G12 (bypass_docking) case, regenerated exactly as tests/golden/make_golden.py did."""
+    name, B, c = case["case"], case["B"], case["c"]
+    X = [dg.uniform(name + "/x0", (B, c), -1, 1), dg.uniform(name + "/x1", (B, c), -1, 1)]
+    dout = dg.uniform(name + "/dout", (B, c), -1, 1)
+    avail = None
+    if case["avail"] == "mixed":
+        avail = np.array([[1, 1], [1, 0], [0, 1]], dtype=np.float32)[dg.integers(name + "/avail_t", (B,), 3)]
+    p = None if case["p"] == "none" else dg.uniform(name + "/p", (B, 2), 0.05, 1.0).astype(np.float32)
+    return X, dout, avail, p
+
+
+def g13_inputs(case):
+    """Inputs of a G13 (M != 2 modalities) case, regenerated exactly as tests/golden/make_golden.py did."""
+    name, B, ds, c, bypass = case["case"], case["B"], case["ds"], case["c"], case["bypass"]
+    M = len(ds)
+    X = [dg.uniform(f"{name}/x{m}", (B, d), -1, 1) for m, d in enumerate(ds)]
+    W = [] if bypass else [dg.weight(f"{name}/w{m}", (c, d), d) for m, d in enumerate(ds)]
+    b = [] if bypass else [dg.weight(f"{name}/b{m}", (c,), d) for m, d in enumerate(ds)]
+    dout = dg.uniform(name + "/dout", (B, c), -1, 1)
+    avail = None
+    if case["avail"] == "mixed":
+        a = dg.integers(name + "/avail", (B, M), 2).astype(np.float32)
+        a[np.arange(B), dg.integers(name + "/avail_keep", (B,), M)] = 1.0
+        avail = a
+    p = None if case["p"] == "none" else dg.uniform(name + "/p", (B, M), 0.05, 1.0).astype(np.float32)
+    return X, W, b, dout, avail, p
+
+
 def model_fill(tag):
     """Parameter filler used for G2/G3/G9 models (same rule as make_golden.build_ref_model)."""
     def fill(key, shape):

@@ -4,7 +4,7 @@ import numpy as np
 import pytest
 import torch
 
-from helpers import Golden, g1_inputs, model_batch, model_fill, unpack_idx
+from helpers import Golden, g1_inputs, g12_inputs, g13_inputs, model_batch, model_fill, unpack_idx
 from oracle import datagen as dg
 from oracle import embrace_oracle as orc
 from oracle import ref_step
@@ -38,6 +38,57 @@ def test_g1_oracle_matches_reference_outputs():
         if case["dtype"] == "f64":
             chk = dg.checksum(E)
             assert abs(chk["sum"] - case["out_chk"]["sum"]) < 1e-9 * max(1.0, case["out_chk"]["abs"])
+
+
+def _chk_equal(a, want):
+    got = dg.checksum(a)
+    return all(abs(got[k] - want[k]) <= 1e-12 * max(1.0, want["abs"]) for k in ("sum", "abs", "dot")) and got["n"] == want["n"]
+
+
+def test_g12_oracle_matches_reference_bypass_docking():
+    g = Golden("G12_bypass_docking")
+    assert len(g.meta["cases"]) == 24
+    for case in g.meta["cases"]:
+        X, dout, avail, p = g12_inputs(case)
+        B, c = case["B"], case["c"]
+        torch.manual_seed(case["seed"])
+        u = torch.rand(B * c, dtype=torch.float64).view(B, c).numpy()
+        idx = orc.embrace_indices(orc.selection_cdf(np.ones((B, 2), np.float32) if p is None else p, avail), u)
+        assert np.array_equal(idx, unpack_idx(g[case["key"] + "_idx"], B, c)), case["tag"]
+        assert int(idx.sum()) == case["idx_ones"]
+        npdt = np.float64 if case["dtype"] == "f64" else np.float32
+        E = orc.embrace_bypass_forward([x.astype(npdt).astype(np.float64) for x in X], idx)
+        dX = orc.embrace_bypass_backward(dout.astype(npdt).astype(np.float64), idx)
+        assert _chk_equal(E, case["out_chk"]) and _chk_equal(dX[0], case["dx0_chk"]) and _chk_equal(dX[1], case["dx1_chk"]), case["tag"]
+
+
+def test_g13_oracle_matches_reference_with_m_modalities():
+    g = Golden("G13_m_modalities")
+    assert len(g.meta["cases"]) == 30 and {len(c["ds"]) for c in g.meta["cases"]} == {1, 3, 4, 8}
+    for case in g.meta["cases"]:
+        X, W, b, dout, avail, p = g13_inputs(case)
+        B, c, M = case["B"], case["c"], len(case["ds"])
+        torch.manual_seed(case["seed"])
+        u = torch.rand(B * c, dtype=torch.float64).view(B, c).numpy()
+        idx = orc.embrace_indices(orc.selection_cdf(np.ones((B, M), np.float32) if p is None else p, avail), u)
+        assert np.array_equal(idx, g[case["key"] + "_idx"]), case["tag"]
+        npdt = np.float64 if case["dtype"] == "f64" else np.float32
+        r = lambda a: a.astype(npdt).astype(np.float64)
+        ref = g[case["key"] + "_out"].astype(np.float64)
+        if case["bypass"]:
+            E = orc.embrace_bypass_forward([r(x) for x in X], idx)
+            dX = orc.embrace_bypass_backward(r(dout), idx, M)
+        else:
+            E, Z = orc.embrace_forward([r(x) for x in X], [r(w) for w in W], [r(v) for v in b], idx)
+            dX, dW, db = orc.embrace_backward(r(dout), [r(x) for x in X], [r(w) for w in W], Z, idx)
+        tol = 1e-12 if (case["dtype"] == "f64" and g[case["key"] + "_out"].dtype == np.float64) else 2e-5
+        assert np.abs(E - ref).max() < tol, case["tag"]
+        ftol = 1e-11 if case["dtype"] == "f64" else 2e-4
+        for m in range(M):
+            assert abs(dg.checksum(dX[m])["dot"] - case["dx_chk"][m]["dot"]) < ftol * max(1.0, case["dx_chk"][m]["abs"]), case["tag"]
+            if not case["bypass"]:
+                assert abs(dg.checksum(dW[m])["dot"] - case["dw_chk"][m]["dot"]) < ftol * max(1.0, case["dw_chk"][m]["abs"])
+                assert abs(dg.checksum(db[m])["dot"] - case["db_chk"][m]["dot"]) < ftol * max(1.0, case["db_chk"][m]["abs"])
 
 
 def test_g4_rng_contract():
