@@ -6,33 +6,38 @@
 
 namespace emb {
 
-// one thread = four consecutive elements of one row: one Philox call (or four injected uniforms), one 4-wide load per
-// modality, one 4-wide store of E and one 32-bit store of the code bytes
-template <typename T, bool VEC4>
+// one thread = G groups of four consecutive elements of one row (G = 2 for 2-byte types when c % 8 == 0, so that every load
+// is 16 bytes per lane): per group one Philox call (or four injected uniforms), one 4-wide load per modality -- all loads are
+// issued before the threshold arithmetic --, one 4-wide store of E and one 32-bit store of the code bytes
+template <typename T, bool VEC4, int G>
 __global__ __launch_bounds__(kThreads) void embrace_bypass_fwd_kernel(const T* __restrict__ X0, const T* __restrict__ X1,
                                                                       const SelArgs sel, const double* __restrict__ u,
                                                                       uint64_t seed, uint64_t step_val,
                                                                       const uint64_t* __restrict__ step_dev, int64_t grow0,
                                                                       T* __restrict__ E, uint8_t* __restrict__ code, int B, int c,
-                                                                      int groups_per_row, long ngroups) {
+                                                                      int threads_per_row, long nthreads) {
+  static_assert(G == 1 || VEC4, "several groups per thread only on the vector path");
   typedef T TV4 __attribute__((ext_vector_type(4)));
-  const long g = (long)blockIdx.x * kThreads + threadIdx.x;
-  if (g >= ngroups) return;
-  const int row = (int)(g / groups_per_row), col = (int)(g % groups_per_row) * 4;
-  const long base = (long)row * c + col;
-  const int nval = VEC4 ? 4 : min(4, c - col);
+  const long t = (long)blockIdx.x * kThreads + threadIdx.x;
+  if (t >= nthreads) return;
+  const int row = (int)(t / threads_per_row), col0 = (int)(t % threads_per_row) * (4 * G);
+  const long base0 = (long)row * c + col0;
 
-  // operands first: the selection arithmetic below overlaps their latency
-  T a[4], b[4];
-  if (VEC4) {
-    const TV4 va = *reinterpret_cast<const TV4*>(X0 + base), vb = *reinterpret_cast<const TV4*>(X1 + base);
+  T a[G][4], b[G][4];
 #pragma unroll
-    for (int j = 0; j < 4; ++j) { a[j] = va[j]; b[j] = vb[j]; }
-  } else {
+  for (int g = 0; g < G; ++g) {
+    const long base = base0 + 4 * g;
+    if (VEC4) {
+      const TV4 va = *reinterpret_cast<const TV4*>(X0 + base), vb = *reinterpret_cast<const TV4*>(X1 + base);
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      a[j] = j < nval ? X0[base + j] : (T)0;
-      b[j] = j < nval ? X1[base + j] : (T)0;
+      for (int j = 0; j < 4; ++j) { a[g][j] = va[j]; b[g][j] = vb[j]; }
+    } else {
+      const int nval = min(4, c - col0);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        a[g][j] = j < nval ? X0[base + j] : (T)0;
+        b[g][j] = j < nval ? X1[base + j] : (T)0;
+      }
     }
   }
 
@@ -43,38 +48,43 @@ __global__ __launch_bounds__(kThreads) void embrace_bypass_fwd_kernel(const T* _
   } else {
     bool ok;
     thr = (double)select_cdf(sel, row, seed, step, grow0, &ok);
-    if (!ok && col == 0) atomicOr(sel.status, EMB_STATUS_INVALID_DISTRIBUTION);
+    if (!ok && col0 == 0) atomicOr(sel.status, EMB_STATUS_INVALID_DISTRIBUTION);
   }
-  bool s1[4];
-  if (u != nullptr) {                      // parity mode: the host generator's doubles (torch.multinomial, :84)
+  const uint64_t t32 = select_threshold32((float)thr);
 #pragma unroll
-    for (int j = 0; j < 4; ++j) s1[j] = thr < (j < nval ? u[base + j] : 0.0);
-  } else {
-    uint32_t w4[4];
-    select_words4(seed, rng_stream(step, EMB_RNG_SELECT), (uint64_t)(grow0 + row) * (uint64_t)c + (uint64_t)col, w4);
-    const uint64_t t32 = select_threshold32((float)thr);
+  for (int g = 0; g < G; ++g) {
+    const int col = col0 + 4 * g;
+    const long base = base0 + 4 * g;
+    const int nval = VEC4 ? 4 : min(4, c - col);
+    bool s1[4];
+    if (u != nullptr) {                      // parity mode: the host generator's doubles (torch.multinomial, :84)
 #pragma unroll
-    for (int j = 0; j < 4; ++j) s1[j] = t32 < (uint64_t)w4[j];
-  }
-
-  T ev[4];
-  uint8_t cv[4];
+      for (int j = 0; j < 4; ++j) s1[j] = thr < (j < nval ? u[base + j] : 0.0);
+    } else {
+      uint32_t w4[4];
+      select_words4(seed, rng_stream(step, EMB_RNG_SELECT), (uint64_t)(grow0 + row) * (uint64_t)c + (uint64_t)col, w4);
 #pragma unroll
-  for (int j = 0; j < 4; ++j) {
-    ev[j] = s1[j] ? b[j] : a[j];           // x_m * 1 + x_other * 0 (:87-88)
-    cv[j] = (uint8_t)(EMB_CODE_ACTIVE | (s1[j] ? (EMB_CODE_IDX | EMB_CODE_KEEP1) : EMB_CODE_KEEP0));
-  }
-  if (VEC4) {
-    TV4 o = {ev[0], ev[1], ev[2], ev[3]};
-    *reinterpret_cast<TV4*>(E + base) = o;
-    *reinterpret_cast<uint32_t*>(code + base) = (uint32_t)cv[0] | ((uint32_t)cv[1] << 8) | ((uint32_t)cv[2] << 16) | ((uint32_t)cv[3] << 24);
-  } else {
+      for (int j = 0; j < 4; ++j) s1[j] = t32 < (uint64_t)w4[j];
+    }
+    T ev[4];
+    uint8_t cv[4];
 #pragma unroll
-    for (int j = 0; j < 4; ++j)
-      if (j < nval) {
-        E[base + j] = ev[j];
-        code[base + j] = cv[j];
-      }
+    for (int j = 0; j < 4; ++j) {
+      ev[j] = s1[j] ? b[g][j] : a[g][j];     // x_m * 1 + x_other * 0 (:87-88)
+      cv[j] = (uint8_t)(EMB_CODE_ACTIVE | (s1[j] ? (EMB_CODE_IDX | EMB_CODE_KEEP1) : EMB_CODE_KEEP0));
+    }
+    if (VEC4) {
+      TV4 o = {ev[0], ev[1], ev[2], ev[3]};
+      *reinterpret_cast<TV4*>(E + base) = o;
+      *reinterpret_cast<uint32_t*>(code + base) = (uint32_t)cv[0] | ((uint32_t)cv[1] << 8) | ((uint32_t)cv[2] << 16) | ((uint32_t)cv[3] << 24);
+    } else {
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+        if (j < nval) {
+          E[base + j] = ev[j];
+          code[base + j] = cv[j];
+        }
+    }
   }
 }
 
@@ -112,18 +122,20 @@ template <typename T> static bool aligned_v4(const void* p) { return (reinterpre
 template <typename T> static int bypass_fwd(const void* X0, const void* X1, const SelArgs& sel, const double* u, uint64_t seed,
                                             uint64_t step_val, const uint64_t* step_dev, int64_t row0, void* E, uint8_t* code,
                                             int B, int c, hipStream_t s) {
-  const int gpr = cdiv(c, 4);
-  const long ngroups = (long)B * gpr;
-  const long nblk = (ngroups + kThreads - 1) / kThreads;
-  EMB_CHECK_ARG(nblk <= 0x7fffffffL, "emb_embrace_bypass_fwd: B*c too large for one launch");
   const bool vec = (c % 4 == 0) && aligned_v4<T>(X0) && aligned_v4<T>(X1) && aligned_v4<T>(E) &&
                    ((reinterpret_cast<uintptr_t>(code) & 3u) == 0);
-  if (vec)
-    embrace_bypass_fwd_kernel<T, true><<<(unsigned)nblk, kThreads, 0, s>>>((const T*)X0, (const T*)X1, sel, u, seed, step_val,
-                                                                            step_dev, row0, (T*)E, code, B, c, gpr, ngroups);
-  else
-    embrace_bypass_fwd_kernel<T, false><<<(unsigned)nblk, kThreads, 0, s>>>((const T*)X0, (const T*)X1, sel, u, seed, step_val,
-                                                                             step_dev, row0, (T*)E, code, B, c, gpr, ngroups);
+  const bool two = vec && sizeof(T) == 2 && (c % 8 == 0) && aligned16(X0) && aligned16(X1) && aligned16(E);
+  const int tpr = two ? c / 8 : cdiv(c, 4);
+  const long nthreads = (long)B * tpr;
+  const long nblk = (nthreads + kThreads - 1) / kThreads;
+  EMB_CHECK_ARG(nblk <= 0x7fffffffL, "emb_embrace_bypass_fwd: B*c too large for one launch");
+#define EMB_BYPASS_LAUNCH(V, GG)                                                                                              \
+  embrace_bypass_fwd_kernel<T, V, GG><<<(unsigned)nblk, kThreads, 0, s>>>((const T*)X0, (const T*)X1, sel, u, seed, step_val, \
+                                                                          step_dev, row0, (T*)E, code, B, c, tpr, nthreads)
+  if (two) EMB_BYPASS_LAUNCH(true, 2);
+  else if (vec) EMB_BYPASS_LAUNCH(true, 1);
+  else EMB_BYPASS_LAUNCH(false, 1);
+#undef EMB_BYPASS_LAUNCH
   EMB_CHECK_LAUNCH();
   return EMB_OK;
 }
