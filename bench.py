@@ -314,7 +314,7 @@ def single_gpu_rate(ea, wl, dtype, device, steps=60, warmup=10):
     return dict(ms_per_step=ms, samples_per_s=B / ms * 1e3)
 
 
-def step_accounting(wl, dims, ms_per_step, stats_csv):
+def step_accounting(wl, dims, ms_per_step, stats_csv, traffic_csv=None):
     """Algorithmic FLOPs / HBM bytes (SURVEY 8d formulas, per launch = per step at this batch) of every kernel class of the
     training step, next to the per-kernel average durations of the committed rocprofv3 --kernel-trace --stats summary of
     this command (profiles/, same binary), and the whole-step line from the live ms_per_step.  Elementwise / pooling
@@ -375,10 +375,17 @@ def step_accounting(wl, dims, ms_per_step, stats_csv):
         table["conv2_wgrad+dgrad"] = (["conv_bwd_dual_kernel"], f1 + f2, b1 + b2)
     if rows:   # classes whose kernels did not run in this step (the other first-block backward)
         table = {cls: v for cls, v in table.items() if not cls.startswith("first_bwd") or any(f in n for f in v[0] for n in rows)}
+    hbm = {}    # kernel name -> HBM bytes per launch from the committed PMC passes of this command (tools/run_pmc_hbm.sh)
+    if traffic_csv and os.path.exists(traffic_csv):
+        for r in csv.DictReader(open(traffic_csv)):
+            hbm[r["kernel"]] = float(r["hbm_MB_per_launch"]) * 1e6
     kernels = {}
     for cls, (frags, fl, by) in table.items():
         us = next((v for f in frags for n, v in rows.items() if f in n), None)
         ent = dict(algorithmic_flops=fl, algorithmic_bytes=by, us_per_launch=us)
+        tr = next((v for f in frags for n, v in hbm.items() if f in n), None)
+        if tr is not None:
+            ent.update(traffic=tr, traffic_over_algorithmic=tr / by)
         if us:
             tf, gbs = fl / us / 1e6, by / us / 1e3
             ent.update(tflops=tf, gbs=gbs, frac=max(tf / peak_tf, gbs / peak_gbs), bound="mfma" if tf / peak_tf >= gbs / peak_gbs else "hbm")
@@ -387,6 +394,7 @@ def step_accounting(wl, dims, ms_per_step, stats_csv):
     total_by = sum(by for _, _, by in table.values())
     us_step = ms_per_step * 1e3
     return dict(kernels=kernels, source=os.path.basename(stats_csv) if rows else None,
+                traffic_source=os.path.basename(traffic_csv) if hbm else None,
                 whole_step=dict(algorithmic_flops=total_fl, algorithmic_bytes=total_by, us=us_step, tflops=total_fl / us_step / 1e6,
                                 gbs=total_by / us_step / 1e3, frac_mfma=total_fl / us_step / 1e6 / peak_tf,
                                 frac_hbm=total_by / us_step / 1e3 / peak_gbs))
@@ -612,7 +620,9 @@ def main():
             roof = dict(kern[dom])
             roof.update(kernel=dom, shapes=dict(B=B, d0=dims[0], d1=dims[1], c=dims[2]), kernels=kern)
             prof = sorted(f for f in os.listdir(os.path.join(ROOT, "profiles")) if f.endswith(f"bench_{args.workload}_kernel_stats.csv"))
-            roof["step"] = step_accounting(wl, dims, result["ms_per_step"], os.path.join(ROOT, "profiles", prof[-1]) if prof else None)
+            pmcs = sorted(f for f in os.listdir(os.path.join(ROOT, "profiles")) if f.endswith("pmc_hbm_per_kernel.csv"))
+            roof["step"] = step_accounting(wl, dims, result["ms_per_step"], os.path.join(ROOT, "profiles", prof[-1]) if prof else None,
+                                           os.path.join(ROOT, "profiles", pmcs[-1]) if pmcs and args.workload == "cfg2" else None)
             result["roofline"] = roof
             extra = {}
             for dt in ("float32", "float64"):                     # the same step at the reference's precision and at fp32
