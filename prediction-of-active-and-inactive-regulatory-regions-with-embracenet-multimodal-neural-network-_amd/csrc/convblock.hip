@@ -554,11 +554,25 @@ __global__ __launch_bounds__(256) void bn_bwd_affine_fin_kernel(const __bf16* __
                                                                 __bf16* __restrict__ dy, int R, int C, int training, int rows_per_block) {
   __shared__ double scratch[256 * 4 + 2 * kBnInlineMaxC];
   __shared__ float fc[2 * kBnInlineMaxC];
-  bn_fin_bwd<256>(fin, C, scratch, fc, blockIdx.x == 0);
   const int TX = C / 8, TY = 256 / TX;
   const int tx = threadIdx.x % TX, ty = threadIdx.x / TX;
-  if (ty >= TY) return;
   const int c0 = tx * 8;
+  // the rows of the workgroup's first chunk do not depend on the finalised sums: they are requested before the prologue, so
+  // that their HBM round trip runs under the prologue's L2 round trip, sums and barriers
+  constexpr int NP = 8;                              // rows_per_block == 8 * TY (launch code): the whole first chunk
+  bf16x8 pz[NP], py[NP];
+  const int rb = blockIdx.x * rows_per_block, rb_end = min(R, rb + rows_per_block);
+#pragma unroll
+  for (int j = 0; j < NP; ++j) {
+    const int r = rb + ty + j * TY;
+    if (ty < TY && r < rb_end) {
+      const long off = (long)r * C + c0;
+      pz[j] = *reinterpret_cast<const bf16x8*>(dy + off);
+      py[j] = *reinterpret_cast<const bf16x8*>(y + off);
+    }
+  }
+  bn_fin_bwd<256>(fin, C, scratch, fc, blockIdx.x == 0);
+  if (ty >= TY) return;
   float A[8], Bc[8], D[8];
 #pragma unroll
   for (int e = 0; e < 8; ++e) {
@@ -567,9 +581,19 @@ __global__ __launch_bounds__(256) void bn_bwd_affine_fin_kernel(const __bf16* __
     Bc[e] = training ? -sc * fc[C + c0 + e] * inv : 0.0f;
     D[e] = training ? sc * (fc[C + c0 + e] * inv * mean - fc[c0 + e]) : 0.0f;
   }
-  for (int r0 = blockIdx.x * rows_per_block; r0 < R; r0 += gridDim.x * rows_per_block) {
+#pragma unroll
+  for (int j = 0; j < NP; ++j) {
+    const int r = rb + ty + j * TY;
+    if (r < rb_end) {
+      bf16x8 o;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) o[e] = (__bf16)(A[e] * (float)pz[j][e] + Bc[e] * (float)py[j][e] + D[e]);
+      *reinterpret_cast<bf16x8*>(dy + (long)r * C + c0) = o;
+    }
+  }
+  for (int r0 = rb; r0 < R; r0 += gridDim.x * rows_per_block) {
     const int r_end = min(R, r0 + rows_per_block);
-    for (int r = r0 + ty; r < r_end; r += TY) {
+    for (int r = r0 + ty + (r0 == rb ? NP * TY : 0); r < r_end; r += TY) {
       const long off = (long)r * C + c0;
       const bf16x8 dzv = *reinterpret_cast<const bf16x8*>(dy + off);
       const bf16x8 yv = *reinterpret_cast<const bf16x8*>(y + off);
