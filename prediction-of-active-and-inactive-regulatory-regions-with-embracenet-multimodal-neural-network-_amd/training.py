@@ -510,6 +510,17 @@ def path_augmentation(augmentation):
     return '_augmentation' if augmentation else ''
 
 
+def get_imbalance(y=None, n_pos=None, n_neg=None, n_decim=3):
+    """positives / negatives rounded to `n_decim` decimals -- the quantity the reference compares with its rebalance
+    threshold (BIOINF_tesi/data_pipe/utils.py:280-306; used at training_models_multimodal.py:533).  A ratio, not a
+    fraction: 10 % positives give 0.111, a positives-majority split gives > 1 (never re-balanced).  No negatives is a
+    ZeroDivisionError, as in the reference."""
+    if y is not None:
+        y = _rows(y).reshape(-1)
+        n_pos, n_neg = int((y == 1).sum()), int((y == 0).sum())
+    return float(np.round(float(n_pos / n_neg), n_decim))
+
+
 def _rows(a):
     """pandas objects / lists of them / arrays -> numpy rows (row order = concatenation order)"""
     if isinstance(a, (list, tuple)):
@@ -562,8 +573,7 @@ class Kfold_CV_Multimodal:
         from . import data
         y_rows = _rows(y).reshape(-1)
         if training:
-            pos = float((y_rows == 1).mean()) if len(y_rows) else 0.0
-            needs = augmentation or min(pos, 1.0 - pos) < self.rebalance_threshold      # get_imbalance(y) < threshold (:600-603)
+            needs = augmentation or get_imbalance(y_rows) < self.rebalance_threshold    # the reference's trigger (:533)
             if needs:
                 if self.rebalance is None:
                     raise NotImplementedError(

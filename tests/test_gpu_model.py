@@ -587,7 +587,7 @@ def test_kfold_cv_driver_runs_on_device_loaders(ea, tmp_path, monkeypatch):
     assert len(cv.scores_dict["final_test_AUPRC_scores"]) == 2 and 0.0 <= cv.scores_dict["average_CV_AUPRC"] <= 1.0
     assert (tmp_path / "models_" / "best.pt").exists()
     with pytest.raises(NotImplementedError):                     # a split the reference would re-balance: loud, not silent
-        cv.rebalance_threshold = 0.45
+        cv.rebalance_threshold = 0.6                             # positives / negatives = 0.35 / 0.65 = 0.54 < 0.6
         cv.build_dataloaders_forCV(X1, X2, y, 16, True, False)
 
 

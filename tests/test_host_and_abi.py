@@ -188,3 +188,31 @@ def test_library_has_no_undefined_internal_symbols():
     out = subprocess.run([nm, "-D", "--undefined-only", _lib.LIB_PATH], capture_output=True, text=True, check=True).stdout
     bad = [l for l in out.splitlines() if "_ZN3emb" in l]
     assert not bad, bad[:5]
+
+
+def test_rebalance_trigger_is_the_reference_ratio(ea, monkeypatch):
+    """Kfold_CV_Multimodal re-balances a training split exactly when the reference does: get_imbalance(y) =
+    round(n_pos / n_neg, 3) < rebalance_threshold (data_pipe/utils.py:280-306, training_models_multimodal.py:533) -- a RATIO:
+    9.5 % positives (ratio 0.105) train as they are at the default threshold 0.1, a positives-majority split never triggers."""
+    from embracenet_amd import data, training
+    assert training.get_imbalance(np.array([1] * 2 + [0] * 19)) == 0.105
+    assert training.get_imbalance(n_pos=1, n_neg=3) == 0.333
+    with pytest.raises(ZeroDivisionError):
+        training.get_imbalance(np.ones(4))
+    seen = []
+    monkeypatch.setattr(data, "device_loaders", lambda *a, **k: seen.append(k.get("balanced")) or "loaders")
+    cv = training.Kfold_CV_Multimodal()
+    cv.rebalance_threshold, cv.random_state, cv.device, cv.precision = 0.1, 789, "cpu", "float32"
+    X1, X2 = np.zeros((210, 3)), np.zeros((210, 8), dtype=np.uint8)
+    y = lambda pos: np.array([1] * pos + [0] * (210 - pos))
+    assert cv.build_dataloaders_forCV(X1, X2, y(20), 16, True, False) == "loaders"      # 20 / 190 = 0.105: no re-balancing
+    assert cv.build_dataloaders_forCV(X1, X2, y(190), 16, True, False) == "loaders"     # ratio 9.5: never
+    with pytest.raises(NotImplementedError):
+        cv.build_dataloaders_forCV(X1, X2, y(17), 16, True, False)                      # 17 / 193 = 0.088 < 0.1
+    with pytest.raises(NotImplementedError):
+        cv.build_dataloaders_forCV(X1, X2, y(100), 16, True, True)                      # augmentation asked for
+    assert cv.build_dataloaders_forCV(X1, X2, y(17), 16, False, False) == "loaders"     # test splits: never
+    calls = []
+    cv.rebalance = lambda X, yy, sequence, thr: (calls.append((sequence, thr)) or (X, yy))
+    assert cv.build_dataloaders_forCV(X1, X2, y(17), 16, True, False) == "loaders" and calls == [(False, 0.1), (True, 0.1)]
+    assert seen == [True, True, False, True]
