@@ -10,8 +10,11 @@
  * Conventions
  *  - plain pointers and sizes only; every pointer is DEVICE memory unless marked "host";
  *  - the caller owns every buffer; the library allocates no device memory.  Host-side state it keeps: the thread-local
- *    error string, the queue of deferred slab reductions (emb_reduce_defer), the registry of packed conv-weight images
- *    (emb_conv_pack_register) and at most one parked rider launch per thread (emb_rider_defer);
+ *    error string, the registry of packed conv-weight images (emb_conv_pack_register) and -- only between an
+ *    emb_reduce_defer / emb_rider_defer call and the matching flush -- launch descriptors parked PER STREAM (queued slab
+ *    reductions, one rider launch, the first conv block's finish / totals jobs).  That state is keyed by the stream and
+ *    mutex-guarded: independent trainers on different streams (from any host threads) do not interact, and emb_reset()
+ *    drops all of it;
  *  - every call only ENQUEUES work on `stream` (a hipStream_t passed as void*), never synchronises,
  *    never reads device memory from the host -> safe under hipGraph stream capture;
  *  - return value: 0 on success, negative EMB_ERR_* otherwise (text via emb_last_error());
@@ -40,7 +43,7 @@
 extern "C" {
 #endif
 
-#define EMB_ABI_VERSION 1
+#define EMB_ABI_VERSION 2
 
 enum { EMB_F32 = 0, EMB_BF16 = 1, EMB_F64 = 2 };
 enum { EMB_OK = 0, EMB_ERR_ARG = -1, EMB_ERR_DTYPE = -2, EMB_ERR_ALIGN = -3, EMB_ERR_LAUNCH = -4 };
@@ -183,16 +186,17 @@ int emb_nadam_step(void* param, const void* grad, void* exp_avg, void* exp_avg_s
                    int dtype, emb_stream_t stream);
 
 /* Riders (csrc/rider.h).  The epigenomic MLP stack (FFNN_pre.py) and the sequence CNN (CNN_pre.py) are independent until the
- * EmbraceNet layer joins them; the MLP launches are tiny and latency-bound.  With deferral armed on the calling thread
- * (emb_rider_defer(1)), an emb_mlp_fwd / emb_mlp_bwd call that takes the bf16 matrix-core kernels (widths % 16 == 0, F % 8 == 0)
+ * EmbraceNet layer joins them; the MLP launches are tiny and latency-bound.  With deferral armed on a stream
+ * (emb_rider_defer(stream, 1)), an emb_mlp_fwd / emb_mlp_bwd call that takes the bf16 matrix-core kernels (widths % 16 == 0, F % 8 == 0)
  * does NOT launch: it is parked and carried as the first workgroups of the next carrier launch on the same stream --
  * emb_convblock_fwd's statistics pass of the fused first block for a forward, emb_convblock_bwd's BatchNorm gather pass of a
- * stored-activation block for a backward -- so the two chains overlap on the CUs without a second stream.  emb_rider_defer(0)
- * disarms (a parked launch stays parked); emb_rider_flush() launches a parked rider on its own.  The optimizer and reduction
+ * stored-activation block for a backward -- so the two chains overlap on the CUs without a second stream.  emb_rider_defer(stream, 0)
+ * disarms (a parked launch stays parked); emb_rider_flush(stream) launches a parked rider on its own.  The optimizer and reduction
  * entry points flush first.  The caller keeps every tensor of a parked launch alive, and does not read its outputs, until a
- * carrier has run or the flush.  At most one rider is parked per thread (parking a second one flushes the first). */
-int emb_rider_defer(int on);
-int emb_rider_flush(void);
+ * carrier has run or the flush.  At most one rider is parked per stream (parking a second one flushes the first); the slot belongs to the
+ * stream, not to the calling thread (autograd runs backward nodes on its own thread). */
+int emb_rider_defer(emb_stream_t stream, int on);
+int emb_rider_flush(emb_stream_t stream);
 
 /* Small MLP stacks fused into one forward launch and two backward launches (FFNN_pre.py:18-49; the post stack
  * and the Linear(->2) head of EmbraceNetMultimodal.py:134-154).  L <= 4 layers, Y_l = dropout(relu(Y_{l-1} W_l^T +
@@ -309,16 +313,25 @@ int emb_convblock_first_linear(int on);
 
 /* Slab reductions.  The weight-gradient kernels of emb_embrace_bwd / emb_linear_bwd / emb_mlp_bwd / emb_convblock_bwd write
  * per-slice partial sums into the caller's workspace and finish with a (deterministic, fixed-order) reduction launch.
- * After emb_reduce_defer(1) those reductions are only queued; emb_reduce_flush(stream) runs ALL queued ones in one launch.
- * Until the flush the parameter gradients are incomplete and every workspace handed to a queued call must stay untouched
- * (give each call site its own workspace).  Process-wide switch, default off (immediate).
+ * After emb_reduce_defer(stream, 1) the reductions of calls on THAT stream are only queued; emb_reduce_flush(stream) runs all of
+ * the stream's queued ones in one launch.  Until the flush the parameter gradients are incomplete and every workspace handed to
+ * a queued call must stay untouched (give each call site its own workspace).  Per-stream switch, default off (immediate).
  * The multi-tensor optimizer entry points (emb_adam_step_multi / emb_rmsprop_step_multi / emb_nadam_step_multi) CONSUME queued
  * jobs: a job whose outputs are gradient tensors of the launch is taken off the queue and its slices are summed inside the
  * optimizer launch (fixed order: same result as the reduction launch, which then is not needed at all); the summed gradient is
  * also stored to the gradient tensor.  Jobs that are not claimed stay queued for emb_reduce_flush.  Both entry points first
  * launch a parked rider (emb_rider_flush), which may be the producer of a queued slab. */
-int emb_reduce_defer(int on);
+int emb_reduce_defer(emb_stream_t stream, int on);
 int emb_reduce_flush(emb_stream_t stream);
+/* Parked launch descriptors (queued reductions, rider, first-block finish / totals jobs) of `stream`, or of every stream when
+ * all_streams != 0.  0 after a completed step. */
+int emb_parked_count(emb_stream_t stream, int all_streams);
+/* Drops everything parked on every stream WITHOUT launching it and returns every defer switch to off: the recovery call after an
+ * exception between a deferring call and its flush (the parked descriptors point at tensors that may be gone).  Returns the
+ * number of descriptors dropped.  Touches no device memory. */
+int emb_reset(void);
+/* The same for ONE stream (what a trainer calls when its step raised between a deferring call and the flush). */
+int emb_reset_stream(emb_stream_t stream);
 
 /* ---- classifier head + loss in one launch (rows a11-a13 of SURVEY 8 fused) ------------------------------------
  * emb_head_ce      logits[B][2] T = E[B][K] . W[2][K]^T + bias (the final nn.Linear(width, 2), EmbraceNetMultimodal.py:151-154,

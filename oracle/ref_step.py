@@ -115,13 +115,19 @@ class OracleEmbraceNetMultimodal(torch.nn.Module):
                 g = F.dropout(g, L["p"], True)
         return h, g.reshape(g.shape[0], -1)
 
-    def forward(self, x, is_training=False, embracenet_dropout=True, generator=None):
+    def forward(self, x, is_training=False, embracenet_dropout=True, generator=None, inject=None):
+        """inject = dict(t=int64 [B] or None, u=fp64 [B, c]): the random draws of :178-182 / :84 handed in instead of taken from
+        the torch generator (tests replaying the engine's device RNG, csrc/philox.h); the arithmetic is unchanged."""
         x1, x2 = x
         B = x1.shape[0]
         h0, h1 = self.pre_nets(x1, x2)
         avail = torch.ones(B, 2)
         r = t = None
-        if is_training and embracenet_dropout:                      # :178-182
+        if inject is not None:
+            t = inject.get("t")
+            if t is not None:
+                avail = F.one_hot(torch.as_tensor(t, dtype=torch.int64), 2).float()
+        elif is_training and embracenet_dropout:                    # :178-182
             r = torch.rand(1, generator=generator)[0]
             if r >= 0.5:
                 t = torch.round(torch.rand([B], generator=generator)).to(torch.int64)
@@ -131,7 +137,10 @@ class OracleEmbraceNetMultimodal(torch.nn.Module):
         if not bool(torch.isfinite(p).all()):
             raise RuntimeError("invalid multinomial distribution (encountering probability entry = infinity or NaN)")
         cdf0 = p[:, 0] / (p[:, 0] + p[:, 1])                        # ATen multinomial cdf, fp32
-        u = torch.rand(B * self.c, dtype=torch.float64, generator=generator).view(B, self.c)
+        if inject is not None:
+            u = torch.as_tensor(inject["u"], dtype=torch.float64).view(B, self.c)
+        else:
+            u = torch.rand(B * self.c, dtype=torch.float64, generator=generator).view(B, self.c)
         idx = cdf0.double()[:, None] < u                            # True -> modality 1
         D0 = F.relu(F.linear(h0, *[getattr(self, n) for n in self.dock[0]]))
         D1 = F.relu(F.linear(h1, *[getattr(self, n) for n in self.dock[1]]))

@@ -47,8 +47,8 @@ SIGNATURES = {
     "emb_mlp_supported": [_i, _vp, _i, _i],
     "emb_mlp_workspace_bytes": [_i, _vp, _i, _i, _i],
     "emb_mlp_fwd": [_vp] * 9 + [_i, _i, _i, _u64, _u64, _vp, _i64, _i, _vp],
-    "emb_rider_defer": [_i],
-    "emb_rider_flush": [],
+    "emb_rider_defer": [_vp, _i],
+    "emb_rider_flush": [_vp],
     "emb_mlp_bwd": [_vp] * 11 + [_i, _i, _i, _vp, _i64, _i, _vp],
     "emb_adam_step_multi": [_vp] * 6 + [_i, _d, _d, _d, _d, _d, _u64, _vp, _i, _vp],
     "emb_rmsprop_step_multi": [_vp] * 5 + [_i, _d, _d, _d, _d, _i, _vp],
@@ -67,8 +67,11 @@ SIGNATURES = {
     "emb_head_ce_finish": [_vp, _vp, _vp, _vp, _vp, _i, _i, _vp],
     "emb_gather_rows": [_vp, _vp, _vp, _i, _vp, _i64, _i64, _vp],
     "emb_mt19937_shuffle": [_vp, _vp, _vp, _i64],
-    "emb_reduce_defer": [_i],
+    "emb_reduce_defer": [_vp, _i],
     "emb_reduce_flush": [_vp],
+    "emb_parked_count": [_vp, _i],
+    "emb_reset": [],
+    "emb_reset_stream": [_vp],
     "emb_convblock_needs_y": [_i, _i, _i, _i, _i, _i],
     "emb_convblock_stats_elems": [_i, _i, _i, _i, _i, _i],
     "emb_convblock_first_linear": [_i],
@@ -106,7 +109,7 @@ def lib():
                           "emb_convblock_stats_elems": ctypes.c_int64,
                           "emb_mlp_workspace_bytes": ctypes.c_int64,
                           "emb_head_ce_workspace_bytes": ctypes.c_int64}.get(name, ctypes.c_int)
-        if L.emb_abi_version() != 1:
+        if L.emb_abi_version() != 2:
             raise RuntimeError("libembrace_hip.so ABI version mismatch")
         _lib = L
     return _lib

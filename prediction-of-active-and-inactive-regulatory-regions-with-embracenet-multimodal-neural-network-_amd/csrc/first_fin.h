@@ -20,10 +20,10 @@ struct FirstFinArgs {
   double count;             // rows behind the batch statistics (B * L)
 };
 
-// deferred mode (emb_reduce_defer): parks the job (one slot; a second submit launches the first); else launches the finish kernel
+// deferred mode (emb_reduce_defer): parks the job (one slot per stream; a second submit launches the first); else launches the finish kernel
 int first_fin_submit(const FirstFinArgs& f, hipStream_t s);
-bool first_fin_peek(FirstFinArgs* out);      // the parked job, if any (stays parked)
-void first_fin_drop();                       // the optimizer launch took it over
+bool first_fin_peek(hipStream_t s, FirstFinArgs* out);   // the job parked on this stream, if any (stays parked)
+void first_fin_drop(hipStream_t s);                      // the optimizer launch took it over
 int first_fin_flush(hipStream_t s);          // launches a parked job the classic way (emb_reduce_flush, or an optimizer call that cannot take it)
 int first_fin_launch(const FirstFinArgs& f, hipStream_t s);   // conv_first.hip
 
@@ -37,8 +37,8 @@ struct GramJobsArgs {
   float* tot;               // [4096] totals
   int B, L, rows, parts;
 };
-void gram_jobs_park(const GramJobsArgs& a, hipStream_t s);    // (one slot: a set parked earlier is launched first)
-bool gram_jobs_take(GramJobsArgs* out);                       // a carrier launch takes the parked set over
+void gram_jobs_park(const GramJobsArgs& a, hipStream_t s);    // (one slot per stream: a set parked earlier is launched first)
+bool gram_jobs_take(hipStream_t s, GramJobsArgs* out);        // a carrier launch of this stream takes the parked set over
 int gram_jobs_flush(hipStream_t s);
 int gram_jobs_launch(const GramJobsArgs& a, hipStream_t s);   // conv_first.hip
 int gram_jobs_count();                                        // kGramJobs

@@ -259,7 +259,7 @@ extern "C" int emb_head_ce(const void* E, const void* W, const void* bias, const
   a.stats = a.slab + (long)nblk * 2 * (K + 1);
   a.tick_a = tick_a; a.tick_b = tick_b; a.B = B; a.K = K;
   a.nblk = nblk;
-  a.njobs = gram_jobs_take(&a.jobs) ? gram_jobs_count() : 0;
+  a.njobs = gram_jobs_take((hipStream_t)stream, &a.jobs) ? gram_jobs_count() : 0;
   const size_t lds = (size_t)4 * 2 * KS * 256 * sizeof(float);
   hipStream_t s = (hipStream_t)stream;
 #define EMB_HEAD_LAUNCH(TT, KK) head_ce_kernel<TT, KK><<<nblk + a.njobs, 256, lds, s>>>(a)

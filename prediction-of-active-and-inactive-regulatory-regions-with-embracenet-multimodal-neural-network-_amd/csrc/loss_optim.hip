@@ -589,7 +589,7 @@ template <typename P, int OPT>
 static int multi_launch(void* const* params, const void* const* grads, void* const* s1, void* const* s2, void* const* shadows,
                         const int64_t* sizes, int ntensors, const Hyper& h, hipStream_t s) {
   {   // a parked rider launch (rider.h) may be the producer of a slab this launch is about to consume
-    const int rcr = rider_flush();
+    const int rcr = rider_flush(s);
     if (rcr != EMB_OK) return rcr;
   }
   for (int off = 0; off < ntensors; off += kMaxTensors) {
@@ -602,7 +602,7 @@ static int multi_launch(void* const* params, const void* const* grads, void* con
     int fft[4] = {-1, -1, -1, -1};
     FirstFinArgs ffj{};
     bool have_ff = false;
-    if (sizeof(P) == 4 && first_fin_peek(&ffj)) {
+    if (sizeof(P) == 4 && first_fin_peek(s, &ffj)) {
       for (int i = 0; i < cnt; ++i) {
         const void* gp = grads[off + i];
         if (gp == nullptr) continue;
@@ -610,7 +610,7 @@ static int multi_launch(void* const* params, const void* const* grads, void* con
       }
       have_ff = fft[0] >= 0 && fft[2] >= 0 && fft[3] >= 0 && ffj.C <= 1024;
       if (have_ff) {
-        first_fin_drop();
+        first_fin_drop(s);
       } else {
         const int rcf = first_fin_flush(s);   // not ours: the classic launch
         if (rcf != EMB_OK) return rcf;
@@ -643,7 +643,7 @@ static int multi_launch(void* const* params, const void* const* grads, void* con
         }
         // a queued slab reduction that would have produced this gradient: its slices are summed in this launch (reduce.h)
         ReduceClaim cl;
-        if (plain && reduce_claim(grads[j], sizeof(P) == 8, &cl)) {
+        if (plain && reduce_claim(s, grads[j], sizeof(P) == 8, &cl)) {
           int k = -1;
           for (int q = 0; q < nsrc; ++q)
             if (a.slab[q].in == cl.job.in && a.slab[q].per == cl.job.per) k = q;
@@ -682,7 +682,7 @@ static int multi_launch(void* const* params, const void* const* grads, void* con
     }
     a.nstats = 0;
     ReduceJob sj;
-    while (a.nstats < 2 && off + cnt >= ntensors && reduce_claim_stats(sizeof(P) == 8, &sj)) {   // (last chunk of the call only)
+    while (a.nstats < 2 && off + cnt >= ntensors && reduce_claim_stats(s, sizeof(P) == 8, &sj)) {   // (last chunk of the call only)
       SlabSrc& d = a.stats[a.nstats];
       d.in = sj.in; d.per = sj.per; d.S = sj.S; d.kind = sj.kind; d.lanes = 1;
       a.stats_loss[a.nstats] = (float*)sj.out[0];

@@ -367,7 +367,7 @@ static int mlp_fwd_t(const void* x, const void* const* W, const void* const* b, 
       if (lds <= 150 * 1024) {
         Rider r{};
         r.kind = RIDER_MLP_FWD; r.nwg = cdiv(B, 16); r.lds = lds; r.stream = s; r.fa = a; r.fl = lay;
-        if (rider_deferring()) {   // carried by the next suitable launch of this stream (rider.h)
+        if (rider_deferring(s)) {   // carried by the next suitable launch of this stream (rider.h)
           rider_park(r);
           return EMB_OK;
         }
@@ -419,7 +419,7 @@ static int mlp_bwd_t(const void* x, const void* const* W, const void* const* h, 
       if (lds <= 150 * 1024) {
         Rider r{};
         r.kind = RIDER_MLP_BWD; r.nwg = nblk; r.lds = lds; r.stream = s; r.ba = a; r.bl = lay;
-        if (rider_deferring() && reduce_deferring()) {   // (an immediate reduction launch below would overtake a parked producer)
+        if (rider_deferring(s) && reduce_deferring(s)) {   // (an immediate reduction launch below would overtake a parked producer)
           rider_park(r);
         } else {
           const int rc = rider_launch(r);

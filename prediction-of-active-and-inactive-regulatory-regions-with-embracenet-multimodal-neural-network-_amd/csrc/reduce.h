@@ -18,9 +18,9 @@ struct ReduceJob {
   int iv[9];         // RJ_LINEAR: N, pitch (row = [N values | bias | pad], pitch 0 = N + 1);  RJ_CONV: Cin, cin_pad, k;  RJ_MLP: L, N_0..3, K_0..3
 };
 
-// immediate mode: launches on `s`; deferred mode: queued until emb_reduce_flush().  is_double selects P.
+// immediate mode: launches on `s`; deferred mode (per stream): queued on `s` until emb_reduce_flush(s).  is_double selects P.
 int reduce_submit(const ReduceJob& job, bool is_double, hipStream_t s);
-bool reduce_deferring();   // submitted jobs are queued (emb_reduce_defer) rather than launched at once
+bool reduce_deferring(hipStream_t s);   // jobs submitted on this stream are queued (emb_reduce_defer) rather than launched at once
 
 // Queued jobs as seen by the multi-tensor optimizer launch (loss_optim.hip), which sums the slices of a gradient itself
 // instead of reading the reduced tensor: `reduce_claim` looks for a queued job with an output == `grad`, returns its
@@ -30,8 +30,8 @@ struct ReduceClaim {
   ReduceJob job;
   int which;         // index into job.out
 };
-bool reduce_claim(const void* grad, bool is_double, ReduceClaim* out);
-bool reduce_claim_stats(bool is_double, ReduceJob* out);
+bool reduce_claim(hipStream_t s, const void* grad, bool is_double, ReduceClaim* out);
+bool reduce_claim_stats(hipStream_t s, bool is_double, ReduceJob* out);
 
 // where element i of output `which` of a job lives inside one slice (the inverse of the scatter in reduce.hip)
 __host__ __device__ inline long reduce_slab_index(int kind, const int* iv, int which, long i) {

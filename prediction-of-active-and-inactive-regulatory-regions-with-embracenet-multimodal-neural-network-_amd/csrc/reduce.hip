@@ -1,4 +1,6 @@
 // One kernel for all slab reductions (see reduce.h).
+#include <map>
+#include <mutex>
 #include <vector>
 
 #include "reduce.h"
@@ -103,14 +105,30 @@ template <typename P> __global__ __launch_bounds__(256) void multi_reduce_kernel
   }
 }
 
-struct Pending {
+// ---- everything a stream has parked (reduce.h, first_fin.h, rider.h): process state keyed by the stream, guarded by one mutex.
+// Two trainers in one process (each on its own stream, from any threads -- autograd runs backward nodes on its own device
+// thread) never see each other's jobs; the same stream used from several threads is the caller's ordering problem, as with any
+// enqueue.  Nothing here owns device memory: a lot only holds launch descriptors (raw pointers the caller keeps alive).
+struct Lot {
+  bool reduce_defer = false, rider_defer = false;
   std::vector<ReduceJob> f32, f64;
+  FirstFinArgs fin{};
+  bool fin_valid = false;
+  GramJobsArgs jobs{};
+  bool jobs_valid = false;
+  Rider rider{};
+  bool idle() const { return f32.empty() && f64.empty() && !fin_valid && !jobs_valid && rider.kind == RIDER_NONE; }
+  int parked() const { return (int)f32.size() + (int)f64.size() + (fin_valid ? 1 : 0) + (jobs_valid ? 1 : 0) + (rider.kind != RIDER_NONE ? 1 : 0); }
 };
-static Pending& pending() {
-  static Pending p;
-  return p;
+static std::recursive_mutex& lot_mutex() {
+  static std::recursive_mutex m;
+  return m;
 }
-static bool g_defer = false;
+static std::map<hipStream_t, Lot>& lots() {
+  static std::map<hipStream_t, Lot> m;
+  return m;
+}
+#define EMB_LOT(var, stream) std::lock_guard<std::recursive_mutex> lot_guard__(emb::lot_mutex()); emb::Lot& var = emb::lots()[(stream)]
 
 template <typename P> static int launch_jobs(const ReduceJob* jobs, int n, hipStream_t s) {
   for (int off = 0; off < n; off += kMaxJobs) {
@@ -137,9 +155,10 @@ template <typename P> static int launch_jobs(const ReduceJob* jobs, int n, hipSt
 
 static int job_outputs(const ReduceJob& j) { return j.kind == RJ_MLP ? 8 : 2; }
 
-bool reduce_claim(const void* grad, bool is_double, ReduceClaim* out) {
+bool reduce_claim(hipStream_t st, const void* grad, bool is_double, ReduceClaim* out) {
   if (grad == nullptr) return false;
-  std::vector<ReduceJob>& v = is_double ? pending().f64 : pending().f32;
+  EMB_LOT(lot, st);
+  std::vector<ReduceJob>& v = is_double ? lot.f64 : lot.f32;
   for (size_t i = 0; i < v.size(); ++i) {
     if (v[i].kind == RJ_HEAD_STATS) continue;
     const int no = job_outputs(v[i]);
@@ -157,8 +176,9 @@ bool reduce_claim(const void* grad, bool is_double, ReduceClaim* out) {
   return false;
 }
 
-bool reduce_claim_stats(bool is_double, ReduceJob* out) {
-  std::vector<ReduceJob>& v = is_double ? pending().f64 : pending().f32;
+bool reduce_claim_stats(hipStream_t st, bool is_double, ReduceJob* out) {
+  EMB_LOT(lot, st);
+  std::vector<ReduceJob>& v = is_double ? lot.f64 : lot.f32;
   for (size_t i = 0; i < v.size(); ++i)
     if (v[i].kind == RJ_HEAD_STATS) {
       *out = v[i];
@@ -171,78 +191,147 @@ bool reduce_claim_stats(bool is_double, ReduceJob* out) {
 int launch_jobs_f32(const ReduceJob* jobs, int n, hipStream_t s) { return launch_jobs<float>(jobs, n, s); }
 int launch_jobs_f64(const ReduceJob* jobs, int n, hipStream_t s) { return launch_jobs<double>(jobs, n, s); }
 
-bool reduce_deferring() { return g_defer; }
+bool reduce_deferring(hipStream_t s) {
+  EMB_LOT(lot, s);
+  return lot.reduce_defer;
+}
 
 // ---- the parked finish of the first conv block's recompute-free backward (first_fin.h)
-static FirstFinArgs g_fin;
-static bool g_fin_valid = false;
 int first_fin_flush(hipStream_t s) {
-  if (!g_fin_valid) return EMB_OK;
-  g_fin_valid = false;
-  return first_fin_launch(g_fin, s);
+  EMB_LOT(lot, s);
+  if (!lot.fin_valid) return EMB_OK;
+  lot.fin_valid = false;
+  return first_fin_launch(lot.fin, s);
 }
 int first_fin_submit(const FirstFinArgs& f, hipStream_t s) {
-  if (!g_defer) return first_fin_launch(f, s);
-  const int rc = first_fin_flush(s);   // (one slot)
+  EMB_LOT(lot, s);
+  if (!lot.reduce_defer) return first_fin_launch(f, s);
+  const int rc = first_fin_flush(s);   // (one slot per stream)
   if (rc != EMB_OK) return rc;
-  g_fin = f;
-  g_fin_valid = true;
+  lot.fin = f;
+  lot.fin_valid = true;
   return EMB_OK;
 }
-bool first_fin_peek(FirstFinArgs* out) {
-  if (g_fin_valid) *out = g_fin;
-  return g_fin_valid;
+bool first_fin_peek(hipStream_t s, FirstFinArgs* out) {
+  EMB_LOT(lot, s);
+  if (lot.fin_valid) *out = lot.fin;
+  return lot.fin_valid;
 }
-void first_fin_drop() { g_fin_valid = false; }
+void first_fin_drop(hipStream_t s) {
+  EMB_LOT(lot, s);
+  lot.fin_valid = false;
+}
 
 // ---- the parked totals jobs of the first conv block's lag statistics (first_fin.h)
-static GramJobsArgs g_jobs;
-static bool g_jobs_valid = false;
 int gram_jobs_flush(hipStream_t s) {
-  if (!g_jobs_valid) return EMB_OK;
-  g_jobs_valid = false;
-  return gram_jobs_launch(g_jobs, s);
+  EMB_LOT(lot, s);
+  if (!lot.jobs_valid) return EMB_OK;
+  lot.jobs_valid = false;
+  return gram_jobs_launch(lot.jobs, s);
 }
 void gram_jobs_park(const GramJobsArgs& a, hipStream_t s) {
+  EMB_LOT(lot, s);
   (void)gram_jobs_flush(s);
-  g_jobs = a;
-  g_jobs_valid = true;
+  lot.jobs = a;
+  lot.jobs_valid = true;
 }
-bool gram_jobs_take(GramJobsArgs* out) {
-  if (!g_jobs_valid) return false;
-  *out = g_jobs;
-  g_jobs_valid = false;
+bool gram_jobs_take(hipStream_t s, GramJobsArgs* out) {
+  EMB_LOT(lot, s);
+  if (!lot.jobs_valid) return false;
+  *out = lot.jobs;
+  lot.jobs_valid = false;
+  return true;
+}
+
+// ---- the parked rider launch (rider.h)
+bool rider_deferring(hipStream_t s) {
+  EMB_LOT(lot, s);
+  return lot.rider_defer;
+}
+int rider_flush(hipStream_t s) {
+  EMB_LOT(lot, s);
+  if (lot.rider.kind == RIDER_NONE) return EMB_OK;
+  const Rider r = lot.rider;
+  lot.rider.kind = RIDER_NONE;
+  return rider_launch(r);
+}
+void rider_park(const Rider& r) {
+  EMB_LOT(lot, r.stream);
+  (void)rider_flush(r.stream);
+  lot.rider = r;
+}
+bool rider_take(hipStream_t s, int kind, Rider* out) {
+  EMB_LOT(lot, s);
+  if (lot.rider.kind != kind) return false;
+  *out = lot.rider;
+  lot.rider.kind = RIDER_NONE;
   return true;
 }
 
 int reduce_submit(const ReduceJob& job, bool is_double, hipStream_t s) {
   if (job.per <= 0 || job.S <= 0) return EMB_OK;
-  if (g_defer) {
-    std::vector<ReduceJob>& v = is_double ? pending().f64 : pending().f32;
-    v.push_back(job);
-    return EMB_OK;
+  {
+    EMB_LOT(lot, s);
+    if (lot.reduce_defer) {
+      (is_double ? lot.f64 : lot.f32).push_back(job);
+      return EMB_OK;
+    }
   }
   return is_double ? launch_jobs<double>(&job, 1, s) : launch_jobs<float>(&job, 1, s);
 }
 
 }  // namespace emb
 
-extern "C" int emb_reduce_defer(int on) {
-  emb::g_defer = on != 0;
+extern "C" int emb_reduce_defer(emb_stream_t stream, int on) {
+  EMB_LOT(lot, (hipStream_t)stream);
+  lot.reduce_defer = on != 0;
   return EMB_OK;
 }
 
+extern "C" int emb_rider_defer(emb_stream_t stream, int on) {
+  EMB_LOT(lot, (hipStream_t)stream);
+  lot.rider_defer = on != 0;
+  return EMB_OK;
+}
+extern "C" int emb_rider_flush(emb_stream_t stream) { return emb::rider_flush((hipStream_t)stream); }
+
 extern "C" int emb_reduce_flush(emb_stream_t stream) {
-  emb::Pending& p = emb::pending();
-  int rc = emb::rider_flush();   // a parked launch may be the producer of a queued slab
+  hipStream_t s = (hipStream_t)stream;
+  EMB_LOT(lot, s);
+  int rc = emb::rider_flush(s);   // a parked launch may be the producer of a queued slab
   if (rc != EMB_OK) return rc;
-  rc = emb::gram_jobs_flush((hipStream_t)stream);
+  rc = emb::gram_jobs_flush(s);
   if (rc != EMB_OK) return rc;
-  rc = emb::first_fin_flush((hipStream_t)stream);
+  rc = emb::first_fin_flush(s);
   if (rc != EMB_OK) return rc;
-  if (!p.f32.empty()) rc = emb::launch_jobs<float>(p.f32.data(), (int)p.f32.size(), (hipStream_t)stream);
-  if (rc == EMB_OK && !p.f64.empty()) rc = emb::launch_jobs<double>(p.f64.data(), (int)p.f64.size(), (hipStream_t)stream);
-  p.f32.clear();
-  p.f64.clear();
+  if (!lot.f32.empty()) rc = emb::launch_jobs<float>(lot.f32.data(), (int)lot.f32.size(), s);
+  if (rc == EMB_OK && !lot.f64.empty()) rc = emb::launch_jobs<double>(lot.f64.data(), (int)lot.f64.size(), s);
+  lot.f32.clear();
+  lot.f64.clear();
   return rc;
+}
+
+extern "C" int emb_parked_count(emb_stream_t stream, int all_streams) {
+  std::lock_guard<std::recursive_mutex> g(emb::lot_mutex());
+  int n = 0;
+  for (auto& kv : emb::lots())
+    if (all_streams || kv.first == (hipStream_t)stream) n += kv.second.parked();
+  return n;
+}
+
+extern "C" int emb_reset(void) {
+  std::lock_guard<std::recursive_mutex> g(emb::lot_mutex());
+  int n = 0;
+  for (auto& kv : emb::lots()) n += kv.second.parked();
+  emb::lots().clear();   // descriptors only: nothing is launched, nothing is freed; defer flags return to "off"
+  return n;
+}
+
+extern "C" int emb_reset_stream(emb_stream_t stream) {
+  std::lock_guard<std::recursive_mutex> g(emb::lot_mutex());
+  auto it = emb::lots().find((hipStream_t)stream);
+  if (it == emb::lots().end()) return 0;
+  const int n = it->second.parked();
+  emb::lots().erase(it);
+  return n;
 }

@@ -5,9 +5,9 @@
 // The chains overlap on the CUs without a second stream (fork / join edges in a captured graph cost more than they hide here:
 // measured 0.248 vs 0.239 ms per step).
 //
-// Protocol (host side, per thread): emb_rider_defer(1) arms deferral; an eligible emb_mlp_fwd / emb_mlp_bwd then parks its
+// Protocol (host side, per STREAM; state in reduce.hip): emb_rider_defer(stream, 1) arms deferral; an eligible emb_mlp_fwd / emb_mlp_bwd then parks its
 // launch instead of issuing it; the next carrier launch on the same stream (first-block statistics pass for the forward, the
-// BatchNorm backward gather pass for the backward) takes it; emb_rider_flush() launches whatever is still parked on its own.
+// BatchNorm backward gather pass for the backward) takes it; emb_rider_flush(stream) launches whatever is still parked on its own.
 // The caller keeps every tensor of a parked launch alive until the flush.
 #pragma once
 #include "mlp_args.h"
@@ -28,10 +28,10 @@ struct Rider {
   MmBwdLayout bl;
 };
 
-bool rider_deferring();                                   // deferral armed on this thread
-void rider_park(const Rider& r);                          // (flushes a previously parked one first)
+bool rider_deferring(hipStream_t s);                      // deferral armed on this stream
+void rider_park(const Rider& r);                          // into r.stream's slot (flushes a previously parked one first)
 bool rider_take(hipStream_t s, int kind, Rider* out);     // a parked rider of that kind on that stream, removed from the slot
-int rider_flush();                                        // EMB_OK or a launch error
+int rider_flush(hipStream_t s);                           // EMB_OK or a launch error
 int rider_launch(const Rider& r);                         // stand-alone launch of a rider's body
 
 }  // namespace emb

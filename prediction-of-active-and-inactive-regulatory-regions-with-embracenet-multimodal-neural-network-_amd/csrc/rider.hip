@@ -1,4 +1,4 @@
-// Parking slot and stand-alone launches of riders (rider.h).
+// Stand-alone launches of riders (rider.h); the parking slot is per-stream state in reduce.hip.
 #include "rider.h"
 
 namespace emb {
@@ -11,11 +11,6 @@ __global__ __launch_bounds__(64) void rider_mlp_bwd_kernel(const MlpBwdArgs<__bf
   extern __shared__ __attribute__((aligned(16))) char rider_smem[];
   mlp_bwd_mfma_body(a, lay, (int)blockIdx.x, rider_smem);
 }
-
-static thread_local bool t_defer = false;
-static thread_local Rider t_slot{};
-
-bool rider_deferring() { return t_defer; }
 
 int rider_launch(const Rider& r) {
   static bool attr = false;
@@ -30,31 +25,4 @@ int rider_launch(const Rider& r) {
   return EMB_OK;
 }
 
-int rider_flush() {
-  if (t_slot.kind == RIDER_NONE) return EMB_OK;
-  const Rider r = t_slot;
-  t_slot.kind = RIDER_NONE;
-  return rider_launch(r);
-}
-
-void rider_park(const Rider& r) {
-  (void)rider_flush();
-  t_slot = r;
-}
-
-bool rider_take(hipStream_t s, int kind, Rider* out) {
-  if (t_slot.kind != kind || t_slot.stream != s) return false;
-  *out = t_slot;
-  t_slot.kind = RIDER_NONE;
-  return true;
-}
-
 }  // namespace emb
-
-using namespace emb;
-
-extern "C" int emb_rider_defer(int on) {
-  t_defer = on != 0;
-  return EMB_OK;
-}
-extern "C" int emb_rider_flush(void) { return rider_flush(); }

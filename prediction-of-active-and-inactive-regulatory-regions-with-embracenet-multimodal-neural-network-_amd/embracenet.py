@@ -308,10 +308,7 @@ class EmbraceNetMultimodal(nn.Module, _RngMixin):
             self._sel_dev, self._sel_key = sp.detach().to(device=dev, dtype=torch.float32).view(1, 2), key
         p = self._sel_dev
         prep = None
-        if T == torch.bfloat16 and not (self.FFNN.use_hip and self.CNN.use_hip):
-            with torch.autocast("cuda", dtype=torch.bfloat16):          # stock-operator A/B path only
-                h0, h1 = self.FFNN(x_FFNN, rng=rng), self.CNN(x_CNN, rng=rng)
-        elif x_FFNN.is_cuda and (getattr(self, "overlap_prenets", False) or os.environ.get("EMB_OVERLAP_PRENETS")):
+        if x_FFNN.is_cuda and (getattr(self, "overlap_prenets", False) or os.environ.get("EMB_OVERLAP_PRENETS")):
             # OPT-IN (model.overlap_prenets = True): the two pre-networks are independent, so the epigenomic MLP and the
             # selection cdf can run on a side stream next to the sequence CNN (autograd replays each node on its forward
             # stream, so the backward chains overlap as well; fork/join by events = graph edges under capture).  It paid
@@ -333,7 +330,7 @@ class EmbraceNetMultimodal(nn.Module, _RngMixin):
             # kernel; its autograd node is attached after the CNN's, so its backward runs first and is carried by the CNN's
             # BatchNorm-backward pass.  (ride_prenets = False, or a stack the fused kernels do not take: plain launches.)
             handle = None
-            if rng is not None and getattr(self, "ride_prenets", True) and self.CNN.use_hip and T == torch.bfloat16:
+            if rng is not None and getattr(self, "ride_prenets", True) and T == torch.bfloat16:
                 handle = self.FFNN.prelaunch(x_FFNN, rng=rng)
             if handle is not None:
                 h1 = self.CNN(x_CNN, rng=rng)

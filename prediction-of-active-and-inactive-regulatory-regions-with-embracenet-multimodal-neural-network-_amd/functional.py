@@ -459,7 +459,7 @@ _FIN_KEEP = []       # BatchNorm vectors + lag statistics of the first conv bloc
 
 def rider_flush():
     """Issue a parked rider launch on its own if no carrier took it (csrc/rider.h) and release its tensors."""
-    check(_lib.lib().emb_rider_flush(), "emb_rider_flush")
+    check(_lib.lib().emb_rider_flush(stream()), "emb_rider_flush")
     _RIDER_KEEP.clear()
 
 
@@ -482,13 +482,13 @@ def _mlp_launch(x, rng, T, meta, params, park=False):
     ilid = (_ct.c_int * L_)(*[int(m[2]) for m in meta])
     L = _lib.lib()
     if park:
-        check(L.emb_rider_defer(1), "emb_rider_defer")
+        check(L.emb_rider_defer(stream(), 1), "emb_rider_defer")
     try:
         check(L.emb_mlp_fwd(ptr(xc), _parr(Ws), _parr(bs), _parr(hs), _parr(masks), iN, irelu, fdrop, ilid, L_, B, Fin,
                             rng.seed, rng.step_val, ptr(rng.step_dev), rng.row0, DTYPE_CODE[T], stream()), "emb_mlp_fwd")
     finally:
         if park:
-            check(L.emb_rider_defer(0), "emb_rider_defer")
+            check(L.emb_rider_defer(stream(), 0), "emb_rider_defer")
     if park:
         _RIDER_KEEP.extend([xc, *Ws, *bs, *hs, *[m for m in masks if m is not None]])
     return xc, Ws, hs, masks, Ns
@@ -536,16 +536,19 @@ class _MlpFn(torch.autograd.Function):
         ws = _workspace(dev, max(need, 1 << 22), ctx.ws_tag)
         irelu = (_ct.c_int * L_)(*[int(r) for r in relus])
         fdrop = (_ct.c_float * L_)(*drops)
-        if ctx.ride:                           # parked for the BatchNorm-backward pass of the conv stack (csrc/rider.h)
-            check(_lib.lib().emb_rider_defer(1), "emb_rider_defer")
+        # parked for the BatchNorm-backward pass of the conv stack (csrc/rider.h) -- unless the caller wants the input gradient:
+        # autograd hands dx on (a cast, AccumulateGrad's copy) as soon as this node returns, i.e. before a parked launch has run
+        ride = ctx.ride and dx is None
+        if ride:
+            check(_lib.lib().emb_rider_defer(stream(), 1), "emb_rider_defer")
         try:
             check(_lib.lib().emb_mlp_bwd(ptr(xc), _parr(Ws), _parr(hs), _parr(masks), ptr(dy), ptr(dx), _parr(dWs), _parr(dbs), iN, irelu,
                                          fdrop, L_, B, Fin, ptr(ws), ws.numel(), DTYPE_CODE[T], stream()), "emb_mlp_bwd")
         finally:
-            if ctx.ride:
-                check(_lib.lib().emb_rider_defer(0), "emb_rider_defer")
-        if ctx.ride:
-            _RIDER_KEEP.extend([xc, dy, *Ws, *hs, *[m for m in masks if m is not None]] + ([dx] if dx is not None else []))
+            if ride:
+                check(_lib.lib().emb_rider_defer(stream(), 0), "emb_rider_defer")
+        if ride:
+            _RIDER_KEEP.extend([xc, dy, *Ws, *hs, *[m for m in masks if m is not None]])
         cast = lambda g, d: None if g is None else (g if g.dtype == d else g.to(d))
         grads = []
         for l in range(L_):
@@ -746,11 +749,27 @@ def reduce_defer(enable):
     """Queue the weight-gradient slab reductions of the backward kernels instead of launching one per layer; `reduce_flush()`
     then runs them all in ONE launch.  Between the two the parameter gradients are incomplete (training.StepRunner and
     bench.py bracket `backward()` with them).  See include/embrace_hip.h."""
-    check(_lib.lib().emb_reduce_defer(int(bool(enable))), "emb_reduce_defer")
+    check(_lib.lib().emb_reduce_defer(stream(), int(bool(enable))), "emb_reduce_defer")
 
 
 def reduce_flush():
     check(_lib.lib().emb_reduce_flush(stream()), "emb_reduce_flush")
+
+
+def parked_count(all_streams=False):
+    """Launch descriptors the library holds for the current stream (or all streams): queued slab reductions, a parked rider, the
+    first conv block's parked finish / totals jobs.  0 after a completed step."""
+    return int(_lib.lib().emb_parked_count(stream(), int(bool(all_streams))))
+
+
+def reset(all_streams=False):
+    """Drop everything parked on the current stream (or on every stream) WITHOUT launching it, switch deferral off and release
+    the tensors kept alive for parked launches: the recovery call after a step raised between a deferring call and its flush
+    (training.StepRunner does it).  Returns the number of descriptors dropped."""
+    L = _lib.lib()
+    n = int(L.emb_reset() if all_streams else L.emb_reset_stream(stream()))
+    _RIDER_KEEP.clear()
+    return n
 
 
 def _workspace(device, nbytes, tag=""):

@@ -9,7 +9,8 @@ same order, same ``output_size`` attribute and the same state-dict keys ``model.
 The ``nn.Sequential`` members only HOLD the parameters (names, shapes, init, ``weight_reset``); on a ROCm
 device ``forward`` runs the hand-written kernels: FFNN_pre = fused Linear+ReLU+Dropout GEMMs
 (csrc/linear.hip), CNN_pre = conv-as-GEMM on a channels-last im2col view + fused BN/ReLU/MaxPool
-(csrc/convblock.hip).  ``use_hip = False`` falls back to the stock torch operators (kept for A/B timing).
+(csrc/convblock.hip).  There is no stock-operator path in the product: the tests that compare against stock torch
+operators call the ``nn.Sequential`` members themselves (tests/helpers.stock_prenets).
 """
 import torch.nn as nn
 
@@ -40,11 +41,8 @@ class FFNN_pre(nn.Module):
         self.output_size = width
         self.model = nn.Sequential(*stack)
         self.compute_dtype = None
-        self.use_hip = True
 
     def forward(self, x, rng=None):
-        if not self.use_hip:                                 # explicit A/B switch only; CPU tensors raise in the HIP path
-            return self.model(x)
         T = self.compute_dtype or self.model[0].weight.dtype
         mods = list(self.model)
         layers = [(mods[i].weight, mods[i].bias, True, float(mods[i + 2].p) if self.training else 0.0, _FFNN_LAYER_ID0 + i // 3)
@@ -54,7 +52,7 @@ class FFNN_pre(nn.Module):
     def prelaunch(self, x, rng=None):
         """Forward whose launch is parked to ride on the sequence CNN's first kernel (functional.mlp_prelaunch); returns a
         handle for `attach`, or None when the stack does not qualify (call the module then)."""
-        if not self.use_hip or not x.is_cuda:
+        if not x.is_cuda:
             return None
         T = self.compute_dtype or self.model[0].weight.dtype
         mods = list(self.model)
@@ -86,16 +84,12 @@ class CNN_pre(nn.Module):
         self.output_size = channels * length
         self.CNN_model = nn.Sequential(*stack)
         self.compute_dtype = None
-        self.use_hip = True
         # data parallelism: False = every rank normalises with the statistics of its own rows (throughput default, what
         # torch DDP does); True = BatchNorm statistics of the GLOBAL batch, i.e. the single-process result of the
         # reference (CNN_pre.py:41), at one small all-reduce per block and direction.
         self.sync_batchnorm = False
 
     def forward(self, x, rng=None):
-        if not self.use_hip:                                 # explicit A/B switch only; CPU tensors raise in the HIP path
-            y = self.CNN_model(x)
-            return y.reshape(y.size(0), -1)
         mods = list(self.CNN_model)
         layers = []
         for i in range(0, len(mods), 5):

@@ -299,12 +299,16 @@ class StepRunner:
             # the loss is the root of the graph: d loss / d logits comes from the loss kernel (or, fused, is already inside
             # the head's node, which ignores what it is handed)
             output.backward(dlogits if dlogits is not None else output.detach())
-        finally:
+        except BaseException:
             F_.set_after_embrace_backward(None)
             if deferred:
-                F_.reduce_defer(False)
-                if not consume:
-                    F_.reduce_flush()   # ... and run in one launch here
+                F_.reset()              # whatever this stream has parked points at tensors of a step that will not finish
+            raise
+        F_.set_after_embrace_backward(None)
+        if deferred:
+            F_.reduce_defer(False)
+            if not consume:
+                F_.reduce_flush()       # ... and run in one launch here
         if self._redundant:
             self._drop_redundant((table.loss[slots_before:table.n], table.counts[slots_before:table.n]))
         if self.flat is not None:
@@ -315,11 +319,15 @@ class StepRunner:
             self.optimizer.external_tick = True             # already advanced by the loss kernel of this step
         try:
             self.optimizer.step()
+        except BaseException:
+            if deferred:
+                F_.reset()
+            raise
         finally:
             if self.opt_tick is not None:
                 self.optimizer.external_tick = False
-            if consume:
-                F_.reduce_flush()       # whatever the optimizer launch did not take (normally nothing: no launch)
+        if consume:
+            F_.reduce_flush()           # whatever the optimizer launch did not take (normally nothing: no launch)
         return output, loss
 
     def _eval_step_eager(self, x_1, x_2, target, table):

@@ -82,3 +82,25 @@ def model_fill(tag):
 
 def model_batch(tag, B, F_in, pos_rate=0.1):
     return (dg.features(tag + "/x1", B, F_in), dg.onehot_sequence(tag + "/x2", B), dg.labels(tag + "/y", B, pos_rate))
+
+
+class stock_prenets:
+    """Context manager: run a model's two pre-networks on the STOCK torch operators their nn.Sequential members hold (the
+    reference's own forward, FFNN_pre.py:47-49 / CNN_pre.py:72-76) instead of the HIP kernels -- the comparison side of the
+    pre-network tests.  The fusion layer and the post stack keep running the HIP path."""
+
+    def __init__(self, model):
+        self.model = model
+
+    def __enter__(self):
+        f, c = self.model.FFNN, self.model.CNN
+        f.forward = lambda x, rng=None: f.model(x)
+        c.forward = lambda x, rng=None: (lambda y: y.reshape(y.size(0), -1))(c.CNN_model(x))
+        f.prelaunch = lambda x, rng=None: None
+        return self.model
+
+    def __exit__(self, *exc):
+        for m in (self.model.FFNN, self.model.CNN):
+            m.__dict__.pop("forward", None)
+        self.model.FFNN.__dict__.pop("prelaunch", None)
+        return False

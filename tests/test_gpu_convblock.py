@@ -126,7 +126,7 @@ def test_conv_stack_is_deterministic_and_dropout_scales(ea):
 
 
 def test_full_model_hip_prenets_match_stock_operators(ea):
-    """same model, same batch: HIP pre-nets vs the stock torch operators (use_hip=False) agree in fp64."""
+    """same model, same batch: HIP pre-nets vs the stock torch operators (helpers.stock_prenets) agree in fp64."""
     from oracle.configs import CONFIGS, FixedTrial
     hp, F_in = CONFIGS["cfg1"]
     m = ea.EmbraceNetMultimodal(FixedTrial(hp), "A549", "active_E_vs_inactive_E", DEV, F_in).double().to(DEV).set_rng("host")
@@ -134,14 +134,16 @@ def test_full_model_hip_prenets_match_stock_operators(ea):
     x2 = torch.from_numpy(dg.onehot_sequence("fm/x2", 48)).to(DEV)
     m.train()
     outs = []
+    import contextlib
+    from helpers import stock_prenets
     for hip in (True, False):
-        m.FFNN.use_hip = m.CNN.use_hip = hip
-        for bn in [mod for mod in m.modules() if isinstance(mod, torch.nn.BatchNorm1d)]:
-            bn.reset_running_stats()
-        torch.manual_seed(11)
-        out = m([x1, x2], is_training=True)
-        m.zero_grad()
-        out.square().sum().backward()
+        with (contextlib.nullcontext() if hip else stock_prenets(m)):
+            for bn in [mod for mod in m.modules() if isinstance(mod, torch.nn.BatchNorm1d)]:
+                bn.reset_running_stats()
+            torch.manual_seed(11)
+            out = m([x1, x2], is_training=True)
+            m.zero_grad()
+            out.square().sum().backward()
         outs.append((out.detach().clone(), m.CNN.CNN_model[0].weight.grad.clone(), m.FFNN.model[0].weight.grad.clone(),
                      m.CNN.CNN_model[1].running_var.clone()))
     for a, b in zip(*outs):

@@ -12,7 +12,7 @@ import numpy as np
 import pytest
 import torch
 
-from helpers import Golden, model_batch, model_fill, unpack_idx
+from helpers import Golden, model_batch, model_fill, stock_prenets, unpack_idx
 from oracle import datagen as dg
 from oracle.configs import CONFIGS, FixedTrial
 
@@ -298,7 +298,7 @@ class _RandomTrial:
 @pytest.mark.parametrize("seed", range(24))
 def test_random_points_of_the_search_space(ea, seed):
     """Shape coverage: two dozen random architectures of the reference's search space.  (1) fp64 eval logits of the HIP path
-    equal the same module run on stock torch operators (use_hip = False for the pre-nets, fusion still HIP) to 1e-9;
+    equal the same module run on stock torch operators (helpers.stock_prenets for the pre-nets, fusion still HIP) to 1e-9;
     (2) fp32 and bf16 training steps through StepRunner (fused head where its shape rules allow, three launches otherwise)
     run, give finite losses and move the parameters."""
     from embracenet_amd import optim, training
@@ -312,9 +312,8 @@ def test_random_points_of_the_search_space(ea, seed):
     a, b = torch.from_numpy(x1).to(DEV), torch.from_numpy(x2).to(DEV)
     with torch.no_grad():
         torch.manual_seed(5); z_hip = model([a, b])
-        model.FFNN.use_hip = model.CNN.use_hip = False
-        torch.manual_seed(5); z_ref = model([a, b])
-        model.FFNN.use_hip = model.CNN.use_hip = True
+        with stock_prenets(model):
+            torch.manual_seed(5); z_ref = model([a, b])
     assert (z_hip - z_ref).abs().max().item() < 1e-9 * max(1.0, z_ref.abs().max().item()), trial.asked
     for precision in ("float32", "bfloat16"):
         m = training.prepare_model(copy.deepcopy(model), DEV, precision).set_rng("philox", seed=seed)

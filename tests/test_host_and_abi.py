@@ -26,7 +26,7 @@ def test_library_exports_every_declared_symbol(ea):
     lib = ctypes.CDLL(ea._lib.LIB_PATH)
     for name in declared:
         assert hasattr(lib, name), name
-    assert ea._lib.lib().emb_abi_version() == 1
+    assert ea._lib.lib().emb_abi_version() == 2
 
 
 def test_abi_rejects_bad_arguments_without_touching_a_gpu(ea):
