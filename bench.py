@@ -201,6 +201,7 @@ def kernel_roofline(ea, wl, device):
                                         rng.step_val, None, 0, ptr(E), ptr(code), B, d0, d1, c, code_of, st()), "fwd")
 
     def bwd():
+        F.reduce_defer(True)              # (per stream: event_time_us captures on the graph-capture stream)
         ea._lib.check(L.emb_embrace_bwd(ptr(dE), ptr(code), ptr(x0), ptr(x1), ptr(w0c), ptr(w1c), ptr(dX0), ptr(dX1),
                                         ptr(dW0), ptr(db0), ptr(dW1), ptr(db1), ptr(wsp), wsp.numel(), B, d0, d1, c, code_of,
                                         st()), "bwd")
@@ -208,12 +209,10 @@ def kernel_roofline(ea, wl, device):
     t_f = event_time_us(fwd, 200)
     # the backward kernel alone (its slab reduction is queued, as in the step, where ONE reduction launch serves the whole
     # backward pass; rocprof's per-kernel average in profiles/ is the cross-check for both numbers)
-    F.reduce_defer(True)
     try:
         t_b = event_time_us(bwd, 200)
     finally:
-        F.reduce_defer(False)
-        F.reduce_flush()
+        F.reset(all_streams=True)         # the queued reductions are not wanted: drop them, deferral off again
     K = d0 + d1
     bytes_f = s * B * K + s * c * K + 2 * sp * c + 4 * B + s * B * c + B * c
     bytes_b = s * B * c + B * c + s * B * K + s * c * K + s * B * K + sp * c * K + 2 * sp * c

@@ -225,6 +225,7 @@ class _EmbraceFn(torch.autograd.Function):
         ctx.T = T
         ctx.in_dtypes = (x0.dtype, x1.dtype, w0.dtype, b0.dtype, w1.dtype, b1.dtype)
         ctx.sinks = tuple(grad_sink(q, P) for q in (w0, b0, w1, b1))
+        ctx.ws_owner = w1
         ctx.mark_non_differentiable(code)
         ctx.set_materialize_grads(False)          # no zero tensor for the (non-differentiable) code output
         return E, code
@@ -247,7 +248,7 @@ class _EmbraceFn(torch.autograd.Function):
         sk = ctx.sinks
         dW0, db0 = _out(sk[0], (c, d0), P, dev), _out(sk[1], (c,), P, dev)
         dW1, db1 = _out(sk[2], (c, d1), P, dev), _out(sk[3], (c,), P, dev)
-        ws = _workspace(dev, 1 << 24, "embrace")
+        ws = _workspace(dev, 1 << 24, "embrace", ctx.ws_owner)
         check(_lib.lib().emb_embrace_bwd(ptr(dE), ptr(code), ptr(x0c), ptr(x1c), ptr(w0c), ptr(w1c), ptr(dX0), ptr(dX1),
                                          ptr(dW0), ptr(db0), ptr(dW1), ptr(db1), ptr(ws), ws.numel(), B, d0, d1, c,
                                          DTYPE_CODE[T], stream()), "emb_embrace_bwd")
@@ -413,6 +414,7 @@ class _LinearFn(torch.autograd.Function):
         ctx.save_for_backward(xc, wc, mask)
         ctx.cfg = (T, bool(relu), float(dropout_p), x.dtype, w.dtype, b.dtype)
         ctx.layer_id = int(layer_id)
+        ctx.ws_owner = w
         ctx.sinks = (grad_sink(w, P), grad_sink(b, P))
         return y
 
@@ -427,7 +429,7 @@ class _LinearFn(torch.autograd.Function):
         dx = torch.empty(B, K, dtype=T, device=xc.device) if ctx.needs_input_grad[0] else None
         sk = ctx.sinks
         dw, db = _out(sk[0], (N, K), P, xc.device), _out(sk[1], (N,), P, xc.device)
-        ws = _workspace(xc.device, 1 << 22, f"linear{ctx.layer_id}")
+        ws = _workspace(xc.device, 1 << 22, f"linear{ctx.layer_id}", ctx.ws_owner)
         check(_lib.lib().emb_linear_bwd(ptr(dy), ptr(mask), ptr(xc), ptr(wc), ptr(dx), ptr(dw), ptr(db), int(relu),
                                         dropout_p, ptr(ws), ws.numel(), B, K, N, DTYPE_CODE[T], stream()), "emb_linear_bwd")
         cast = lambda g, d: None if g is None else (g if g.dtype == d else g.to(d))
@@ -511,6 +513,7 @@ class _MlpFn(torch.autograd.Function):
         xc, Ws, hs, masks, Ns = pre
         ctx.save_for_backward(xc, *Ws, *hs, *[m if m is not None else hs[0] for m in masks])
         ctx.ws_tag = f"mlp{int(meta[0][2])}"
+        ctx.ws_owner = params[0]
         ctx.cfg = (T, L_, Ns, [bool(m[0]) for m in meta], [float(m[1]) for m in meta], [m is not None for m in masks],
                    x.dtype, [params[i].dtype for i in range(2 * L_)])
         ctx.sinks = tuple(grad_sink(q, P) for q in params)
@@ -533,7 +536,7 @@ class _MlpFn(torch.autograd.Function):
         dbs = [_out(sk[2 * l + 1], (Ns[l],), P, dev) for l in range(L_)]
         iN = (_ct.c_int * L_)(*Ns)
         need = _lib.lib().emb_mlp_workspace_bytes(Fin, iN, L_, B, DTYPE_CODE[T])
-        ws = _workspace(dev, max(need, 1 << 22), ctx.ws_tag)
+        ws = _workspace(dev, max(need, 1 << 22), ctx.ws_tag, ctx.ws_owner)
         irelu = (_ct.c_int * L_)(*[int(r) for r in relus])
         fdrop = (_ct.c_float * L_)(*drops)
         # parked for the BatchNorm-backward pass of the conv stack (csrc/rider.h) -- unless the caller wants the input gradient:
@@ -692,7 +695,7 @@ class _HeadCEFn(torch.autograd.Function):
         tgt = _as(arm.target.reshape(-1), torch.int64)
         logits = torch.empty(B, 2, dtype=T, device=dev)
         dE = torch.empty(B, K, dtype=T, device=dev) if train else None
-        ws = _workspace(dev, L_.emb_head_ce_workspace_bytes(B, K), "head")
+        ws = _workspace(dev, L_.emb_head_ce_workspace_bytes(B, K), "head", W)
         if len(arm.ticks) > 2:
             raise ValueError("at most two tick counters")
         ta, tb = (list(arm.ticks) + [None, None])[:2]
@@ -772,11 +775,24 @@ def reset(all_streams=False):
     return n
 
 
-def _workspace(device, nbytes, tag=""):
-    """Scratch buffer of call site `tag`: kernels of different streams may run concurrently (the epigenomic pre-network
-    overlaps the sequence pre-network), and a deferred slab reduction still reads one call site's buffer after the next
-    backward kernels have run -- every user keeps its own (and keeps it across steps: nothing is allocated under capture)."""
-    key = (torch.device(device), tag)
+_WS_FINALIZERS = set()
+
+
+def _workspace_drop(owner_id):
+    _WS_FINALIZERS.discard(owner_id)
+    for k in [k for k in _WORKSPACE if k[2] == owner_id]:
+        del _WORKSPACE[k]
+
+
+def _workspace(device, nbytes, tag="", owner=None):
+    """Scratch buffer of call site `tag` of the layer that owns the parameter object `owner`: kernels of different streams may run
+    concurrently, and a deferred slab reduction still reads one call site's buffer after the next backward kernels have run --
+    every (layer, call site) keeps its own, so two models trained side by side in one process never share scratch (and keeps it
+    across steps: nothing is allocated under capture)."""
+    key = (torch.device(device), tag, 0 if owner is None else id(owner))
+    if owner is not None and id(owner) not in _WS_FINALIZERS:     # the scratch dies with the parameter object it belongs to
+        _WS_FINALIZERS.add(id(owner))
+        weakref.finalize(owner, _workspace_drop, id(owner))
     buf = _WORKSPACE.get(key)
     if buf is None or buf.numel() < nbytes:
         if buf is not None:
@@ -857,7 +873,7 @@ class _ConvStackFn(torch.autograd.Function):
             out = torch.empty((B, Cout, Lp) if last else (B, Lp, Cout), dtype=T, device=dev)
             argmax = torch.empty(B, Lp, Cout, dtype=torch.uint8, device=dev)
             nbytes = L_.emb_convblock_workspace_bytes(B, L, cin_pad, Cout, k, code)
-            ws = _workspace(dev, nbytes, f"conv{i}")
+            ws = _workspace(dev, nbytes, f"conv{i}", w)
             sync = bn_sync if training else None
             sums = torch.empty(2 * Cout + 1, dtype=torch.float64, device=dev) if sync is not None else None
             for phase in ((1, 2) if sync is not None else (0,)):
@@ -880,6 +896,7 @@ class _ConvStackFn(torch.autograd.Function):
         ctx.save_for_backward(*saved)
         ctx.cfg = (T, int(training), B, shapes, 0 if x_codes == 2 else x_codes, bn_sync if training else None)   # (backward reads the saved channels-last image)
         ctx.sinks = tuple(grad_sink(tensors[6 * i + j], P) for i in range(n_layers) for j in range(4))
+        ctx.ws_owners = tuple(tensors[6 * i] for i in range(n_layers))
         if _RIDER_KEEP:
             rider_flush()                      # a parked MLP forward that no kernel of this stack carried
         return cur.reshape(B, -1)
@@ -904,7 +921,7 @@ class _ConvStackFn(torch.autograd.Function):
             dW = _out(sk[0], (Cout, Cin, k), P, dev)
             db, dgam, dbeta = (_out(sk[j], (Cout,), P, dev) for j in (1, 2, 3))
             nbytes = L_.emb_convblock_workspace_bytes(B, L, cin_pad, Cout, k, code)
-            ws = _workspace(dev, nbytes, f"conv{i}")
+            ws = _workspace(dev, nbytes, f"conv{i}", ctx.ws_owners[i])
             sums = torch.empty(2 * Cout + 1, dtype=torch.float64, device=dev) if sync is not None else None
             for phase in ((1, 2) if sync is not None else (0,)):
                 check(L_.emb_convblock_bwd(ptr(g), int(last), ptr(argmax), None if fused else ptr(y), ptr(stats), ptr(xin),

@@ -46,8 +46,12 @@ def test_cfg4_network_fp32_eval_and_train_step_vs_oracle(ea):
     the initial (0, 1) so the four BatchNorms are plain affine maps;
     train-mode logits 2e-4: four batch-statistics BatchNorms each divide by a standard deviation formed from fp32 sums, and
     the max-pools pick by comparing neighbouring fp32 values (a different winner changes the value by the rounding distance only);
-    loss 1e-5 absolute; parameter gradients 2e-3 of each tensor's largest gradient (fp32 accumulation over B * L products per
-    weight and the same BatchNorm chain backwards; measured ~1e-4)."""
+    loss 1e-5 absolute; gradients, relative to each tensor's largest gradient: 1e-4 for everything that does not sit behind a
+    max-pool (docking layers, post stack, head, the epigenomic MLP, the last block's BatchNorm affine), 3e-2 for the conv-stack
+    tensors -- not an engine property: stock torch in fp32 on the CPU deviates from its own fp64 run by 8e-4 ... 1.5e-2 on exactly
+    these tensors at this batch (measured in the build container with oracle/ref_step.py built in fp32), because a pooling
+    window whose two largest fp32 values are one rounding apart hands its whole gradient to the other position; the logits do
+    not move (2e-7).  The conv tensors are additionally held to 1e-2 in relative L2 norm."""
     from embracenet_amd import training
     wl = bench.WORKLOADS["cfg4"]
     B = 256
@@ -96,10 +100,13 @@ def test_cfg4_network_fp32_eval_and_train_step_vs_oracle(ea):
             go = oracle_m.tensor(key).grad.numpy()
             gg = params[key].grad.double().cpu().numpy()
             if key.endswith(".bias") and ".CNN_model." in key and int(key.split(".")[2]) % 5 == 0:
-                assert np.abs(gg).max() < 1e-5 * max(1e-3, np.abs(params[key.replace(".bias", ".weight")].grad).max().item())
+                assert np.abs(gg).max() < 1e-5 * max(1e-3, params[key.replace(".bias", ".weight")].grad.abs().max().item())
                 continue                # conv bias in front of a batch-statistics BatchNorm: exactly zero gradient, noise on both sides
-            worst[key] = np.abs(gg - go).max() / max(np.abs(go).max(), 1e-12)
-        bad = {k: v for k, v in worst.items() if not v < 2e-3}
+            behind_pool = ".CNN_model." in key and not key.startswith(f"CNN.CNN_model.{5 * (len(oracle_m.cnn) - 1) + 1}.")
+            worst[key] = (np.abs(gg - go).max() / max(np.abs(go).max(), 1e-12), 3e-2 if behind_pool else 1e-4)
+            if behind_pool:
+                assert np.linalg.norm(gg - go) / max(np.linalg.norm(go), 1e-12) < 1e-2, (seed, key)
+        bad = {k: v for k, v in worst.items() if not v[0] < v[1]}
         assert not bad, (seed, bad)
     assert branches == {True, False}, "seeds no longer cover both modality-dropout branches"
 

@@ -169,7 +169,7 @@ def test_reset_after_an_exception_leaves_no_stale_job(ea):
 def test_reset_drops_parked_descriptors_on_every_stream(ea):
     F = ea.functional
     L, ptr, st = ea._lib.lib(), ea._lib.ptr, ea._lib.stream
-    x = torch.randn(64, 32, device=DEV)
+    x = torch.randn(1024, 32, device=DEV)                   # (large enough for the batch-split weight gradient: a slab job)
     w = torch.randn(16, 32, device=DEV, requires_grad=True)
     b = torch.zeros(16, device=DEV, requires_grad=True)
     s1, s2 = torch.cuda.Stream(), torch.cuda.Stream()
@@ -190,4 +190,4 @@ def test_reset_drops_parked_descriptors_on_every_stream(ea):
         assert F.parked_count() == 0
     torch.cuda.synchronize()
     ref = (torch.relu(x @ w.detach().t() + b.detach()) > 0).float().t() @ x
-    assert torch.allclose(w.grad, ref, rtol=1e-4, atol=1e-4)
+    assert torch.allclose(w.grad, ref, rtol=1e-4, atol=1e-3)
