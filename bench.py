@@ -200,12 +200,24 @@ def kernel_roofline(ea, wl, device):
         ea._lib.check(L.emb_embrace_fwd(ptr(x0), ptr(x1), ptr(w0c), ptr(b0), ptr(w1c), ptr(b1), ptr(cdf0), None, rng.seed,
                                         rng.step_val, None, 0, ptr(E), ptr(code), B, d0, d1, c, code_of, st()), "fwd")
 
+    # the backward as the step runs it: on the pre-masked gradients the classifier head leaves (emb_head_ce_masked) when the
+    # persistent ring GEMM takes the shape (csrc/gemm_jobs.h), else from dE and the code bytes (emb_embrace_bwd)
+    masked = bool(L.emb_embrace_bwd_masked_supported(B, d0, d1, c, code_of))
+    dD0, dD1 = torch.empty_like(dE), torch.empty_like(dE)
+
     def bwd():
         F.reduce_defer(True)              # (per stream: event_time_us captures on the graph-capture stream)
-        ea._lib.check(L.emb_embrace_bwd(ptr(dE), ptr(code), ptr(x0), ptr(x1), ptr(w0c), ptr(w1c), ptr(dX0), ptr(dX1),
-                                        ptr(dW0), ptr(db0), ptr(dW1), ptr(db1), ptr(wsp), wsp.numel(), B, d0, d1, c, code_of,
-                                        st()), "bwd")
+        if masked:
+            ea._lib.check(L.emb_embrace_bwd_masked(ptr(dD0), ptr(dD1), ptr(x0), ptr(x1), ptr(w0c), ptr(w1c), ptr(dX0), ptr(dX1),
+                                                   ptr(dW0), ptr(db0), ptr(dW1), ptr(db1), ptr(wsp), wsp.numel(), B, d0, d1, c,
+                                                   code_of, st()), "bwd_masked")
+        else:
+            ea._lib.check(L.emb_embrace_bwd(ptr(dE), ptr(code), ptr(x0), ptr(x1), ptr(w0c), ptr(w1c), ptr(dX0), ptr(dX1),
+                                            ptr(dW0), ptr(db0), ptr(dW1), ptr(db1), ptr(wsp), wsp.numel(), B, d0, d1, c, code_of,
+                                            st()), "bwd")
     fwd()
+    if masked:
+        ea._lib.check(L.emb_embrace_premask(ptr(dE), ptr(code), ptr(dD0), ptr(dD1), B, c, code_of, st()), "premask")
     t_f = event_time_us(fwd, 200)
     # the backward kernel alone (its slab reduction is queued, as in the step, where ONE reduction launch serves the whole
     # backward pass; rocprof's per-kernel average in profiles/ is the cross-check for both numbers)

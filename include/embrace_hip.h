@@ -350,6 +350,29 @@ int emb_head_ce(const void* E, const void* W, const void* bias, const int64_t* t
                 int K, int dtype, emb_stream_t stream);
 int emb_head_ce_finish(const void* workspace, void* dW, void* db, float* loss, int64_t* confusion, int B, int K,
                        emb_stream_t stream);
+/* emb_head_ce with the fusion layer's backward prepared inside it: when the head sits directly on the EmbraceNet output
+ * (n_post_layers = 0, EmbraceNetMultimodal.py:134-154), `code` = the forward's code bytes [B][K] and dD0 / dD1 [B][K] T receive
+ * the PRE-MASKED gradients dD_m = dE * keep_m (keep_m = EMB_CODE_KEEP0 / KEEP1: selected modality and active ReLU) that
+ * emb_embrace_bwd_masked multiplies -- the mask is applied once, by the kernel that produces dE, instead of per MFMA fragment
+ * in the backward GEMMs.  code, dD0, dD1: all three or none (then identical to emb_head_ce).  dE may be NULL when only the
+ * masked gradients are wanted. */
+int emb_head_ce_masked(const void* E, const void* W, const void* bias, const int64_t* target, int64_t* class_counts,
+                       int global_counts, void* logits, void* dE, const uint8_t* code, void* dD0, void* dD1, void* workspace,
+                       int64_t workspace_bytes, uint64_t* tick_a, uint64_t* tick_b, int B, int K, int dtype, emb_stream_t stream);
+
+/* ---- EmbraceNet backward on pre-masked gradients (csrc/gemm_jobs.h; autograd through EmbraceNetMultimodal.py:52-60,80-88) ----
+ * emb_embrace_premask      dD0 = dE * keep0, dD1 = dE * keep1 (elementwise; for producers of dE other than emb_head_ce_masked);
+ *                          B * c % 8 == 0, EMB_F32 / EMB_BF16.
+ * emb_embrace_bwd_masked   the four GEMMs of emb_embrace_bwd (dX_m = dD_m W_m, dW_m = dD_m^T X_m, db_m = sum_b dD_m) as one
+ *                          persistent launch streaming 32 KB operand stages through a five-slot LDS ring (LDS-DMA, four stages
+ *                          ahead, across tile boundaries).  Same outputs, workspace and slab / reduction contract as
+ *                          emb_embrace_bwd.  EMB_BF16, c % 16 == 0, d0 % 8 == 0, d1 % 8 == 0 (emb_embrace_bwd_masked_supported). */
+int emb_embrace_premask(const void* dE, const uint8_t* code, void* dD0, void* dD1, int B, int c, int dtype, emb_stream_t stream);
+int emb_embrace_bwd_masked_supported(int B, int d0, int d1, int c, int dtype);
+int emb_embrace_bwd_masked(const void* dD0, const void* dD1, const void* X0, const void* X1, const void* W0, const void* W1,
+                           void* dX0, void* dX1, void* dW0, void* db0, void* dW1, void* db1, void* workspace,
+                           int64_t workspace_bytes, int B, int d0, int d1, int c, int dtype, emb_stream_t stream);
+
 
 /* ---- input staging ---------------------------------------------------------------------------
  * The split (features, sequence codes / one-hot windows, labels) stays resident in HBM; a batch is a row gather:

@@ -64,6 +64,10 @@ SIGNATURES = {
     "emb_head_ce_supported": [_i, _i, _i],
     "emb_head_ce_workspace_bytes": [_i, _i],
     "emb_head_ce": [_vp, _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _i64, _vp, _vp, _i, _i, _i, _vp],
+    "emb_head_ce_masked": [_vp, _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _vp, _vp, _i, _i, _i, _vp],
+    "emb_embrace_premask": [_vp, _vp, _vp, _vp, _i, _i, _i, _vp],
+    "emb_embrace_bwd_masked_supported": [_i, _i, _i, _i, _i],
+    "emb_embrace_bwd_masked": [_vp] * 13 + [_i64, _i, _i, _i, _i, _i, _vp],
     "emb_head_ce_finish": [_vp, _vp, _vp, _vp, _vp, _i, _i, _vp],
     "emb_gather_rows": [_vp, _vp, _vp, _i, _vp, _i64, _i64, _vp],
     "emb_mt19937_shuffle": [_vp, _vp, _vp, _i64],

@@ -13,6 +13,7 @@
 #include "gemm_tile.h"
 #include "reduce.h"
 #include "embrace_bwd_split.h"
+#include "gemm_jobs.h"
 #include <cstdlib>
 #include <cstring>
 
@@ -177,7 +178,71 @@ static int bwd_dispatch(const void* dE, const uint8_t* code, const void* X0, con
   return EMB_OK;
 }
 
+// dD_m = dE * keep_m for both modalities in one elementwise pass (8 elements per thread: 16-byte loads of bf16 / two of f32)
+template <typename T> __global__ __launch_bounds__(256) void premask_kernel(const T* __restrict__ dE, const uint8_t* __restrict__ code,
+                                                                           T* __restrict__ dD0, T* __restrict__ dD1, long n8) {
+  constexpr int VEC = Elem<T>::VEC, NV = 8 / VEC;   // 16-byte vectors per thread
+  using V = typename Vec16<T>::type;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n8; i += (long)gridDim.x * 256) {
+    const u32x2 cw = *reinterpret_cast<const u32x2*>(code + i * 8);
+    V v[NV], o0[NV], o1[NV];
+#pragma unroll
+    for (int k = 0; k < NV; ++k) v[k] = *reinterpret_cast<const V*>(dE + i * 8 + k * VEC);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const uint32_t cb = cw[e >> 2] >> (8 * (e & 3));
+      o0[e / VEC][e % VEC] = (cb & EMB_CODE_KEEP0) ? v[e / VEC][e % VEC] : (T)0.0f;
+      o1[e / VEC][e % VEC] = (cb & EMB_CODE_KEEP1) ? v[e / VEC][e % VEC] : (T)0.0f;
+    }
+#pragma unroll
+    for (int k = 0; k < NV; ++k) {
+      *reinterpret_cast<V*>(dD0 + i * 8 + k * VEC) = o0[k];
+      *reinterpret_cast<V*>(dD1 + i * 8 + k * VEC) = o1[k];
+    }
+  }
+}
+
 }  // namespace emb
+
+extern "C" int emb_embrace_premask(const void* dE, const uint8_t* code, void* dD0, void* dD1, int B, int c, int dtype,
+                                   emb_stream_t stream) {
+  EMB_CHECK_ARG(dE && code && dD0 && dD1, "emb_embrace_premask: null pointer");
+  EMB_CHECK_ARG(B > 0 && c > 0 && ((long)B * c) % 8 == 0, "emb_embrace_premask: B * c must be a multiple of 8 (B=%d c=%d)", B, c);
+  EMB_CHECK_ARG(emb::aligned16(dE) && emb::aligned16(dD0) && emb::aligned16(dD1) && (reinterpret_cast<uintptr_t>(code) & 7u) == 0,
+                "emb_embrace_premask: dE, dD0, dD1 must be 16-byte, code 8-byte aligned");
+  const long n8 = (long)B * c / 8;
+  const int blocks = (int)((n8 + 255) / 256 < 2048 ? (n8 + 255) / 256 : 2048);
+  hipStream_t s = (hipStream_t)stream;
+  if (dtype == EMB_BF16) emb::premask_kernel<__bf16><<<blocks, 256, 0, s>>>((const __bf16*)dE, code, (__bf16*)dD0, (__bf16*)dD1, n8);
+  else if (dtype == EMB_F32) emb::premask_kernel<float><<<blocks, 256, 0, s>>>((const float*)dE, code, (float*)dD0, (float*)dD1, n8);
+  else {
+    emb::set_error("emb_embrace_premask: unsupported dtype %d", dtype);
+    return EMB_ERR_DTYPE;
+  }
+  EMB_CHECK_LAUNCH();
+  return EMB_OK;
+}
+
+extern "C" int emb_embrace_bwd_masked_supported(int B, int d0, int d1, int c, int dtype) {
+  return dtype == EMB_BF16 && B > 0 && c % 16 == 0 && d0 % 8 == 0 && d1 % 8 == 0 && d0 > 0 && d1 > 0;
+}
+
+extern "C" int emb_embrace_bwd_masked(const void* dD0, const void* dD1, const void* X0, const void* X1, const void* W0,
+                                      const void* W1, void* dX0, void* dX1, void* dW0, void* db0, void* dW1, void* db1,
+                                      void* workspace, int64_t workspace_bytes, int B, int d0, int d1, int c, int dtype,
+                                      emb_stream_t stream) {
+  EMB_CHECK_ARG(dD0 && dD1 && X0 && X1 && W0 && W1 && dW0 && db0 && dW1 && db1, "emb_embrace_bwd_masked: null pointer");
+  EMB_CHECK_ARG(emb_embrace_bwd_masked_supported(B, d0, d1, c, dtype),
+                "emb_embrace_bwd_masked: unsupported shape / dtype (see emb_embrace_bwd_masked_supported)");
+  static const int force_S = [] { const char* e = getenv("EMB_BWD_S"); return e ? atoi(e) : 0; }();
+  const int rc = emb::gemm_jobs_bwd_dispatch(dD0, dD1, X0, X1, W0, W1, dX0, dX1, dW0, db0, dW1, db1, workspace, workspace_bytes, B,
+                                             d0, d1, c, force_S, (hipStream_t)stream);
+  if (rc == 1) {
+    emb::set_error("emb_embrace_bwd_masked: operands must be 16-byte aligned and smaller than 2 GiB");
+    return EMB_ERR_ARG;
+  }
+  return rc;
+}
 
 extern "C" int emb_embrace_bwd(const void* dE, const uint8_t* code, const void* X0, const void* X1, const void* W0,
                                const void* W1, void* dX0, void* dX1, void* dW0, void* db0, void* dW1, void* db1,

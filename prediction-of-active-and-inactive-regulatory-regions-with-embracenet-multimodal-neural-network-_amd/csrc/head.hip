@@ -30,6 +30,11 @@ struct HeadArgs {
   int global_counts;
   void* logits;
   void* dE;
+  // the fusion layer's code bytes [B][K] (EMB_CODE_KEEP0 / KEEP1) and the two PRE-MASKED gradients dD_m = dE * keep_m the head
+  // writes for emb_embrace_bwd_masked (csrc/gemm_jobs.h) when the head sits directly on the fusion layer (all three or none)
+  const uint8_t* code;
+  void* dD0;
+  void* dD1;
   float* slab;        // [nblk][2][K+1]
   float* stats;       // [nblk][kHeadStats]
   uint64_t* tick_a;
@@ -134,6 +139,7 @@ template <typename T, int KS> __global__ __launch_bounds__(256) void head_ce_ker
   const T* E = (const T*)a.E;
   T* dE = (T*)a.dE;
   T* logits = (T*)a.logits;
+  const bool train = a.dE != nullptr || a.code != nullptr;   // the head's own backward is wanted
   constexpr int RPW = kHeadRows / 4;
 #pragma unroll
   for (int r = 0; r < RPW; ++r) {
@@ -172,7 +178,7 @@ template <typename T, int KS> __global__ __launch_bounds__(256) void head_ce_ker
     pp += (float)pred;
     np_ += (float)y;
     rows += 1.f;
-    if (dE != nullptr) {
+    if (train) {
       const float inv = 1.0f / (e0 + e1);
       const float g = (float)((double)wy / den);
       const float l0 = g * (e0 * inv - (y ? 0.0f : 1.0f)), l1 = g * (e1 * inv - (y ? 1.0f : 0.0f));
@@ -188,14 +194,28 @@ template <typename T, int KS> __global__ __launch_bounds__(256) void head_ce_ker
           ga[s][q] += l0 * e[s][q];
           gb[s][q] += l1 * e[s][q];
         }
-        if (j < K) store4<T>(dE + row * K + j, o);
+        if (j < K) {
+          if (a.code != nullptr) {              // one dword = the code bytes of this lane's four elements
+            const uint32_t cw = *reinterpret_cast<const uint32_t*>(a.code + row * K + j);
+            float o0[4], o1[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+              const uint32_t cb = cw >> (8 * q);
+              o0[q] = (cb & EMB_CODE_KEEP0) ? o[q] : 0.0f;
+              o1[q] = (cb & EMB_CODE_KEEP1) ? o[q] : 0.0f;
+            }
+            store4<T>((T*)a.dD0 + row * K + j, o0);
+            store4<T>((T*)a.dD1 + row * K + j, o1);
+          }
+          if (dE != nullptr) store4<T>(dE + row * K + j, o);
+        }
       }
     }
   }
 
   // the four waves meet in LDS (wave order fixed); one slab row and one statistics row per workgroup
   constexpr int KP = KS * 256;
-  if (dE != nullptr) {
+  if (train) {
 #pragma unroll
     for (int s = 0; s < KS; ++s) {
       f32x4 va = {ga[s][0], ga[s][1], ga[s][2], ga[s][3]}, vb = {gb[s][0], gb[s][1], gb[s][2], gb[s][3]};
@@ -213,7 +233,7 @@ template <typename T, int KS> __global__ __launch_bounds__(256) void head_ce_ker
     sstat[wave][6] = db1;
   }
   __syncthreads();
-  if (dE != nullptr) {
+  if (train) {
     float* out = a.slab + (long)blockIdx.x * 2 * (K + 1);
     for (int q = tid; q < 2 * K; q += 256) {
       const int m = q >= K ? 1 : 0, j = q - m * K;
@@ -244,17 +264,23 @@ extern "C" int64_t emb_head_ce_workspace_bytes(int B, int K) {
   return (int64_t)head_blocks(B) * (2 * (K + 1) + kHeadStats) * (int64_t)sizeof(float);
 }
 
-extern "C" int emb_head_ce(const void* E, const void* W, const void* bias, const int64_t* target, int64_t* class_counts,
-                           int global_counts, void* logits, void* dE, void* workspace, int64_t workspace_bytes, uint64_t* tick_a,
-                           uint64_t* tick_b, int B, int K, int dtype, emb_stream_t stream) {
+extern "C" int emb_head_ce_masked(const void* E, const void* W, const void* bias, const int64_t* target, int64_t* class_counts,
+                                  int global_counts, void* logits, void* dE, const uint8_t* code, void* dD0, void* dD1,
+                                  void* workspace, int64_t workspace_bytes, uint64_t* tick_a, uint64_t* tick_b, int B, int K,
+                                  int dtype, emb_stream_t stream) {
   EMB_CHECK_ARG(E && W && bias && target && class_counts && logits && workspace, "emb_head_ce: null pointer");
   EMB_CHECK_ARG(emb_head_ce_supported(B, K, dtype), "emb_head_ce: unsupported shape / dtype (see emb_head_ce_supported)");
   EMB_CHECK_ARG(workspace_bytes >= emb_head_ce_workspace_bytes(B, K), "emb_head_ce: workspace too small");
   EMB_CHECK_ARG(aligned16(E) && aligned16(W) && (dE == nullptr || aligned16(dE)), "emb_head_ce: E, W and dE must be 16-byte aligned");
+  EMB_CHECK_ARG((code == nullptr) == (dD0 == nullptr) && (code == nullptr) == (dD1 == nullptr),
+                "emb_head_ce_masked: code, dD0 and dD1 go together");
+  EMB_CHECK_ARG(code == nullptr || (aligned16(dD0) && aligned16(dD1) && (reinterpret_cast<uintptr_t>(code) & 3u) == 0),
+                "emb_head_ce_masked: dD0 / dD1 must be 16-byte, code 4-byte aligned");
   const int nblk = head_blocks(B), KS = cdiv(K, 256);
   HeadArgs a{};
   a.E = E; a.W = (const float*)W; a.bias = (const float*)bias; a.target = target; a.class_counts = class_counts;
   a.global_counts = global_counts; a.logits = logits; a.dE = dE;
+  a.code = code; a.dD0 = dD0; a.dD1 = dD1;
   a.slab = (float*)workspace;
   a.stats = a.slab + (long)nblk * 2 * (K + 1);
   a.tick_a = tick_a; a.tick_b = tick_b; a.B = B; a.K = K;
@@ -281,6 +307,13 @@ extern "C" int emb_head_ce(const void* E, const void* W, const void* bias, const
 #undef EMB_HEAD_LAUNCH
   EMB_CHECK_LAUNCH();
   return EMB_OK;
+}
+
+extern "C" int emb_head_ce(const void* E, const void* W, const void* bias, const int64_t* target, int64_t* class_counts,
+                           int global_counts, void* logits, void* dE, void* workspace, int64_t workspace_bytes, uint64_t* tick_a,
+                           uint64_t* tick_b, int B, int K, int dtype, emb_stream_t stream) {
+  return emb_head_ce_masked(E, W, bias, target, class_counts, global_counts, logits, dE, nullptr, nullptr, nullptr, workspace,
+                            workspace_bytes, tick_a, tick_b, B, K, dtype, stream);
 }
 
 extern "C" int emb_head_ce_finish(const void* workspace, void* dW, void* db, float* loss, int64_t* confusion, int B, int K,

@@ -267,7 +267,9 @@ class EmbraceNetMultimodal(nn.Module, _RngMixin):
             if len(layers) > 1:                                  # hidden post layers, then the head takes the loss with it
                 y = F_.mlp(y, layers[:-1], rng=rng, compute_dtype=T)
             w, b = layers[-1][:2]
-            return F_.head_ce(y, w, b, arm, compute_dtype=T)
+            # no hidden post layer: the head reads the fusion layer's output itself and prepares that layer's backward
+            code = self.embracenet.last_code if (len(layers) == 1 and getattr(self, "premask_in_head", True)) else None
+            return F_.head_ce(y, w, b, arm, compute_dtype=T, code=code)
         return F_.mlp(y, layers, rng=rng, compute_dtype=T)
 
     def fused_loss_ready(self, B):

@@ -249,9 +249,20 @@ class _EmbraceFn(torch.autograd.Function):
         dW0, db0 = _out(sk[0], (c, d0), P, dev), _out(sk[1], (c,), P, dev)
         dW1, db1 = _out(sk[2], (c, d1), P, dev), _out(sk[3], (c,), P, dev)
         ws = _workspace(dev, 1 << 24, "embrace", ctx.ws_owner)
-        check(_lib.lib().emb_embrace_bwd(ptr(dE), ptr(code), ptr(x0c), ptr(x1c), ptr(w0c), ptr(w1c), ptr(dX0), ptr(dX1),
-                                         ptr(dW0), ptr(db0), ptr(dW1), ptr(db1), ptr(ws), ws.numel(), B, d0, d1, c,
-                                         DTYPE_CODE[T], stream()), "emb_embrace_bwd")
+        L_ = _lib.lib()
+        # the producer of dE may have left the pre-masked gradients dD_m = dE * keep_m of THIS forward's code bytes (the fused
+        # classifier head does: _HeadCEFn): then the backward is four plain GEMMs (csrc/gemm_jobs.h)
+        pm = _PREMASKED.pop(dE.data_ptr(), None)
+        if pm is not None and not (pm[2] == code.data_ptr() and pm[0].shape == (B, c) and pm[0].dtype == T):
+            pm = None
+        if pm is not None and L_.emb_embrace_bwd_masked_supported(B, d0, d1, c, DTYPE_CODE[T]):
+            check(L_.emb_embrace_bwd_masked(ptr(pm[0]), ptr(pm[1]), ptr(x0c), ptr(x1c), ptr(w0c), ptr(w1c), ptr(dX0), ptr(dX1),
+                                            ptr(dW0), ptr(db0), ptr(dW1), ptr(db1), ptr(ws), ws.numel(), B, d0, d1, c,
+                                            DTYPE_CODE[T], stream()), "emb_embrace_bwd_masked")
+        else:
+            check(L_.emb_embrace_bwd(ptr(dE), ptr(code), ptr(x0c), ptr(x1c), ptr(w0c), ptr(w1c), ptr(dX0), ptr(dX1),
+                                     ptr(dW0), ptr(db0), ptr(dW1), ptr(db1), ptr(ws), ws.numel(), B, d0, d1, c,
+                                     DTYPE_CODE[T], stream()), "emb_embrace_bwd")
         if _AFTER_EMBRACE_BWD is not None:
             _AFTER_EMBRACE_BWD()
         t = ctx.in_dtypes
@@ -262,6 +273,7 @@ class _EmbraceFn(torch.autograd.Function):
 
 
 _AFTER_EMBRACE_BWD = None
+_PREMASKED = {}      # dE.data_ptr() -> (dD0, dD1, code.data_ptr()): left by the producer of dE for the fusion layer's backward
 
 
 def set_after_embrace_backward(fn):
@@ -683,8 +695,9 @@ class _HeadCEFn(torch.autograd.Function):
     (trainers call ``logits.backward(<anything of the right shape>)``)."""
 
     @staticmethod
-    def forward(ctx, E, W, b, T, arm, train):
+    def forward(ctx, E, W, b, T, arm, train, code=None):
         _lib.require_cuda(E, W, b, arm.target)
+        _PREMASKED.clear()
         L_ = _lib.lib()
         B, K = E.shape
         dev = E.device
@@ -699,8 +712,16 @@ class _HeadCEFn(torch.autograd.Function):
         if len(arm.ticks) > 2:
             raise ValueError("at most two tick counters")
         ta, tb = (list(arm.ticks) + [None, None])[:2]
-        check(L_.emb_head_ce(ptr(Ec), ptr(Wc), ptr(bc), ptr(tgt), ptr(arm.class_counts), int(arm.global_counts), ptr(logits),
-                             ptr(dE), ptr(ws), ws.numel(), ptr(ta), ptr(tb), B, K, DTYPE_CODE[T], stream()), "emb_head_ce")
+        # `code`: E is the fusion layer's output and these are its code bytes -- the head also writes the pre-masked gradients
+        # its backward GEMMs multiply (emb_embrace_bwd_masked); dE itself is still written: the fallback stays exact
+        masked = (train and code is not None and tuple(code.shape) == (B, K) and code.is_contiguous()
+                  and L_.emb_embrace_bwd_masked_supported(B, 8, 8, K, DTYPE_CODE[T]))
+        dD0 = torch.empty(B, K, dtype=T, device=dev) if masked else None
+        dD1 = torch.empty(B, K, dtype=T, device=dev) if masked else None
+        check(L_.emb_head_ce_masked(ptr(Ec), ptr(Wc), ptr(bc), ptr(tgt), ptr(arm.class_counts), int(arm.global_counts), ptr(logits),
+                                    ptr(dE), ptr(code) if masked else None, ptr(dD0), ptr(dD1), ptr(ws), ws.numel(), ptr(ta),
+                                    ptr(tb), B, K, DTYPE_CODE[T], stream()), "emb_head_ce_masked")
+        ctx.premasked = (dD0, dD1, code.data_ptr()) if masked else None
         if not train:                                            # evaluation: nothing else will come, finish now
             check(L_.emb_head_ce_finish(ptr(ws), None, None, ptr(arm.loss_out), ptr(arm.confusion), B, K, stream()), "emb_head_ce_finish")
         ctx.keep = (dE, ws, arm.loss_out, arm.confusion, B, K, E.dtype)
@@ -714,15 +735,18 @@ class _HeadCEFn(torch.autograd.Function):
         dW = _out(ctx.sinks[0], (2, K), torch.float32, dev)
         db = _out(ctx.sinks[1], (2,), torch.float32, dev)
         check(_lib.lib().emb_head_ce_finish(ptr(ws), ptr(dW), ptr(db), ptr(loss_out), ptr(confusion), B, K, stream()), "emb_head_ce_finish")
+        if ctx.premasked is not None and dE.dtype == edt:
+            _PREMASKED[dE.data_ptr()] = ctx.premasked
         return (dE if dE.dtype == edt else dE.to(edt), None if ctx.sinks[0] is not None else dW,
-                None if ctx.sinks[1] is not None else db, None, None, None)
+                None if ctx.sinks[1] is not None else db, None, None, None, None)
 
 
-def head_ce(E, W, b, arm, compute_dtype=None):
-    """Final Linear(width, 2) + armed loss (FusedLoss) -> logits; see _HeadCEFn."""
+def head_ce(E, W, b, arm, compute_dtype=None, code=None):
+    """Final Linear(width, 2) + armed loss (FusedLoss) -> logits; see _HeadCEFn.  `code`: E is the output of `embrace` and these
+    are its code bytes (the head then prepares the fusion layer's backward, emb_head_ce_masked)."""
     # (needs_input_grad inside the node does not see torch.no_grad(): decide here whether a backward will follow)
     train = torch.is_grad_enabled() and (E.requires_grad or W.requires_grad or b.requires_grad)
-    return _HeadCEFn.apply(E, W, b, compute_dtype or E.dtype, arm, train)
+    return _HeadCEFn.apply(E, W, b, compute_dtype or E.dtype, arm, train, code if (train and E.requires_grad) else None)
 
 
 def count_labels(target, out=None):

@@ -124,6 +124,59 @@ def test_embrace_forward_backward_vs_oracle(ea, shape, dt):
         assert e < (TOL[dt] * (4 if dt == "bf16" else 10)), (name_, e)
 
 
+MASKED_SHAPES = [s_ for s_ in SHAPES if s_[3] % 16 == 0 and s_[1] % 8 == 0 and s_[2] % 8 == 0] + [(200, 8, 72, 48), (2048, 256, 4096, 512)]
+
+
+@pytest.mark.parametrize("slices", ["default", "one"])
+@pytest.mark.parametrize("shape", MASKED_SHAPES)
+def test_embrace_backward_on_premasked_gradients_vs_oracle(ea, shape, slices):
+    """emb_embrace_premask + emb_embrace_bwd_masked (csrc/gemm_jobs.h: the persistent ring GEMM on dD_m = dE * keep_m) against
+    the oracle's backward, bf16 operands, called through the C ABI.  The pre-masked gradients themselves are bit-exact
+    (a select per element); the GEMM outputs hold the bf16 bar of the fused backward.  `one`: no scratch => every weight
+    gradient tile reduces over the whole batch (no slabs); `default`: batch slices + queued slab reduction."""
+    B, d0, d1, c = shape
+    T, dt = torch.bfloat16, "bf16"
+    BF = ea._lib.DTYPE_CODE[T]
+    name = f"fb/{B}_{d0}_{d1}_{c}"
+    X = [round_to(dg.uniform(name + "/x0", (B, d0)), dt), round_to(dg.uniform(name + "/x1", (B, d1)), dt)]
+    W = [round_to(dg.weight(name + "/w0", (c, d0), d0), dt), round_to(dg.weight(name + "/w1", (c, d1), d1), dt)]
+    b = [round_to(dg.weight(name + "/b0", (c,), d0), "f32"), round_to(dg.weight(name + "/b1", (c,), d1), "f32")]
+    p = dg.uniform(name + "/p", (B, 2), 0.05, 1.0).astype(np.float32)
+    u = dg.uniform(name + "/u", (B, c))
+    dE = round_to(dg.uniform(name + "/dE", (B, c), -1, 1), dt)
+    idx = orc.embrace_indices(orc.selection_cdf(p), u)
+    E, Z = orc.embrace_forward(X, W, b, idx)
+    dX, dW, db = orc.embrace_backward(dE, X, W, Z, idx)
+    F = ea.functional
+    L, ptr, st = ea._lib.lib(), ea._lib.ptr, ea._lib.stream
+    x0, x1 = dev(X[0], T), dev(X[1], T)
+    w0, w1 = dev(W[0], T), dev(W[1], T)
+    cdf0, _ = F.select_prep(dev(p), None, B)
+    with torch.no_grad():
+        _, code = F.embrace(x0, x1, dev(W[0], torch.float32), dev(b[0], torch.float32), dev(W[1], torch.float32),
+                            dev(b[1], torch.float32), cdf0, u=dev(u), compute_dtype=T)
+    dEg = dev(dE, T)
+    dD0, dD1 = torch.empty_like(dEg), torch.empty_like(dEg)
+    ea._lib.check(L.emb_embrace_premask(ptr(dEg), ptr(code), ptr(dD0), ptr(dD1), B, c, BF, st()), "premask")
+    keep0, keep1 = ((code >> 6) & 1).bool(), ((code >> 7) & 1).bool()
+    assert torch.equal(dD0, torch.where(keep0, dEg, torch.zeros_like(dEg))) and torch.equal(dD1, torch.where(keep1, dEg, torch.zeros_like(dEg)))
+    assert not bool((keep0 & keep1).any())
+    dX0, dX1 = torch.full((B, d0), 7.0, dtype=T, device=DEV), torch.full((B, d1), 7.0, dtype=T, device=DEV)
+    dW0, dW1 = torch.full((c, d0), 7.0, device=DEV), torch.full((c, d1), 7.0, device=DEV)
+    db0, db1 = torch.full((c,), 7.0, device=DEV), torch.full((c,), 7.0, device=DEV)
+    ws = torch.empty(1 << 25, dtype=torch.uint8, device=DEV) if slices == "default" else None
+    assert L.emb_embrace_bwd_masked_supported(B, d0, d1, c, BF)
+    ea._lib.check(L.emb_embrace_bwd_masked(ptr(dD0), ptr(dD1), ptr(x0), ptr(x1), ptr(w0), ptr(w1), ptr(dX0), ptr(dX1), ptr(dW0),
+                                           ptr(db0), ptr(dW1), ptr(db1), ptr(ws), 0 if ws is None else ws.numel(), B, d0, d1, c, BF,
+                                           st()), "bwd_masked")
+    torch.cuda.synchronize()
+    for name_, got, want in (("dX0", dX0, dX[0]), ("dX1", dX1, dX[1]), ("dW0", dW0, dW[0]), ("dW1", dW1, dW[1]),
+                             ("db0", db0, db[0]), ("db1", db1, db[1])):
+        s = max(1.0, np.abs(want).max())
+        e = np.abs(host(got) - want).max() / s
+        assert e < TOL[dt] * 4, (name_, e)
+
+
 def test_forward_is_deterministic_and_code_consistent(ea):
     B, d0, d1, c = 128, 16, 1856, 512
     F = ea.functional
