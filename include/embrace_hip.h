@@ -366,7 +366,9 @@ int emb_head_ce_masked(const void* E, const void* W, const void* bias, const int
  * emb_embrace_bwd_masked   the four GEMMs of emb_embrace_bwd (dX_m = dD_m W_m, dW_m = dD_m^T X_m, db_m = sum_b dD_m) as one
  *                          persistent launch streaming 32 KB operand stages through a five-slot LDS ring (LDS-DMA, four stages
  *                          ahead, across tile boundaries).  Same outputs, workspace and slab / reduction contract as
- *                          emb_embrace_bwd.  EMB_BF16, c % 16 == 0, d0 % 8 == 0, d1 % 8 == 0 (emb_embrace_bwd_masked_supported). */
+ *                          emb_embrace_bwd.  EMB_F32 (v_mfma_f32_16x16x4_f32), c % 4 == 0, d0 % 4 == 0, d1 % 4 == 0
+ *                          (emb_embrace_bwd_masked_supported); bf16 keeps emb_embrace_bwd (csrc/embrace_bwd_split.h), which
+ *                          measured faster there. */
 int emb_embrace_premask(const void* dE, const uint8_t* code, void* dD0, void* dD1, int B, int c, int dtype, emb_stream_t stream);
 int emb_embrace_bwd_masked_supported(int B, int d0, int d1, int c, int dtype);
 int emb_embrace_bwd_masked(const void* dD0, const void* dD1, const void* X0, const void* X1, const void* W0, const void* W1,

@@ -224,7 +224,7 @@ extern "C" int emb_embrace_premask(const void* dE, const uint8_t* code, void* dD
 }
 
 extern "C" int emb_embrace_bwd_masked_supported(int B, int d0, int d1, int c, int dtype) {
-  return dtype == EMB_BF16 && B > 0 && c % 16 == 0 && d0 % 8 == 0 && d1 % 8 == 0 && d0 > 0 && d1 > 0;
+  return dtype == EMB_F32 && B > 0 && c % 4 == 0 && d0 % 4 == 0 && d1 % 4 == 0 && d0 > 0 && d1 > 0 && c > 0;
 }
 
 extern "C" int emb_embrace_bwd_masked(const void* dD0, const void* dD1, const void* X0, const void* X1, const void* W0,

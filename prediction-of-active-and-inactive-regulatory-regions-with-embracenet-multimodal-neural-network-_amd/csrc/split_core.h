@@ -149,6 +149,7 @@ __device__ unsigned long long* g_split_prof = nullptr;     // [gridDim][16]: slo
   do {                                                                                                 \
     if (g_split_prof != nullptr && threadIdx.x == 0) {                                                 \
       if ((k) == 2) g_split_prof[(size_t)blockIdx.x * 16 + 1] = __builtin_amdgcn_s_memrealtime();      \
+      if ((k) == 8) g_split_prof[(size_t)blockIdx.x * 16 + 9] = __builtin_amdgcn_s_memrealtime();      \
       g_split_prof[(size_t)blockIdx.x * 16 + (k)] = __builtin_amdgcn_s_memtime();                      \
     }                                                                                                  \
   } while (0)

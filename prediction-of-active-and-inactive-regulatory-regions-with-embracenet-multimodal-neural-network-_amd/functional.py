@@ -255,7 +255,12 @@ class _EmbraceFn(torch.autograd.Function):
         pm = _PREMASKED.pop(dE.data_ptr(), None)
         if pm is not None and not (pm[2] == code.data_ptr() and pm[0].shape == (B, c) and pm[0].dtype == T):
             pm = None
-        if pm is not None and L_.emb_embrace_bwd_masked_supported(B, d0, d1, c, DTYPE_CODE[T]):
+        ok = bool(L_.emb_embrace_bwd_masked_supported(B, d0, d1, c, DTYPE_CODE[T])) and (B * c) % 8 == 0
+        if ok and pm is None:          # another producer of dE (hidden post layers, a plain autograd loss): mask here, once
+            pm = (torch.empty(B, c, dtype=T, device=dev), torch.empty(B, c, dtype=T, device=dev), code.data_ptr())
+            check(L_.emb_embrace_premask(ptr(dE), ptr(code), ptr(pm[0]), ptr(pm[1]), B, c, DTYPE_CODE[T], stream()),
+                  "emb_embrace_premask")
+        if ok:
             check(L_.emb_embrace_bwd_masked(ptr(pm[0]), ptr(pm[1]), ptr(x0c), ptr(x1c), ptr(w0c), ptr(w1c), ptr(dX0), ptr(dX1),
                                             ptr(dW0), ptr(db0), ptr(dW1), ptr(db1), ptr(ws), ws.numel(), B, d0, d1, c,
                                             DTYPE_CODE[T], stream()), "emb_embrace_bwd_masked")

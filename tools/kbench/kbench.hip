@@ -9,6 +9,7 @@
 #include <functional>
 #include <vector>
 #include "embrace_bwd_split.h"
+#include "gemm_jobs.h"
 #include "embrace_split.h"
 
 namespace emb {
@@ -65,6 +66,15 @@ static void report_stamps(unsigned long long* dprof, int nblk, const char* const
       end_max = std::max(end_max, st);
     }
     if (!cnt) continue;
+    {   // in-kernel clock: shader-clock ticks per 100 MHz wall tick between entry and exit (MI355X_MICROARCH.md, DVFS item 6)
+      double ticks = 0, wall = 0;
+      for (int b = 0; b < nblk; ++b) {
+        const unsigned long long* r = &h[(size_t)b * 16];
+        if ((int)r[0] != k || r[2] == 0 || r[9] == 0) continue;
+        ticks += (double)(r[8] - r[2]); wall += (double)(r[9] - r[1]);
+      }
+      if (wall > 0) printf("  %-8s in-kernel clock %.2f GHz\n", kind_names[k], ticks / wall * 0.1);
+    }
     printf("  %-8s n=%4d start avg %.2f max %.2f us | cycles: setup+request %.0f, first wait %.0f, main loop %.0f, park %.0f, tail (store / epilogue) %.0f | total %.0f\n",
            kind_names[k], cnt, start_sum / cnt, start_max, sum[3] / cnt, sum[4] / cnt, sum[5] / cnt, sum[6] / cnt, sum[8] / cnt,
            (sum[3] + sum[4] + sum[5] + sum[6] + sum[8]) / cnt);
@@ -72,8 +82,9 @@ static void report_stamps(unsigned long long* dprof, int nblk, const char* const
 }
 
 int main(int argc, char** argv) {
-  if (argc < 6) { printf("usage: kbench bwd|fwd B d0 d1 c [S]\n"); return 1; }
-  const bool bwd = strcmp(argv[1], "bwd") == 0;
+  if (argc < 6) { printf("usage: kbench bwd|gj|fwd B d0 d1 c [S]\n"); return 1; }
+  const bool gj = strcmp(argv[1], "gj") == 0;             // the persistent ring GEMM on pre-masked gradients (gemm_jobs.h)
+  const bool bwd = strcmp(argv[1], "bwd") == 0 || gj;
   const int B = atoi(argv[2]), d0 = atoi(argv[3]), d1 = atoi(argv[4]), c = atoi(argv[5]), S = argc > 6 ? atoi(argv[6]) : 0;
   hipStream_t s; CK(hipStreamCreate(&s));
   __bf16* X0 = dev_random<__bf16>((size_t)B * d0, 1, 1.0f);
@@ -97,7 +108,14 @@ int main(int argc, char** argv) {
 
   std::function<void()> launch;
   emb::SelArgs sel{cdf0, nullptr, nullptr, nullptr, 0, 0};
-  if (bwd) {
+  float *fX0 = nullptr, *fX1 = nullptr, *fW0 = nullptr, *fW1 = nullptr, *fdE = nullptr, *fdX0 = nullptr, *fdX1 = nullptr;
+  if (gj) {   // fp32 operands
+    fX0 = dev_random<float>((size_t)B * d0, 1, 1.0f); fX1 = dev_random<float>((size_t)B * d1, 2, 1.0f);
+    fW0 = dev_random<float>((size_t)c * d0, 3, 0.1f); fW1 = dev_random<float>((size_t)c * d1, 4, 0.02f);
+    fdE = dev_random<float>((size_t)B * c, 5, 1.0f);
+    CK(hipMalloc(&fdX0, (size_t)B * d0 * 4)); CK(hipMalloc(&fdX1, (size_t)B * d1 * 4));
+    launch = [&] { if (emb::gemm_jobs_bwd_dispatch(fdE, fdE, fX0, fX1, fW0, fW1, fdX0, fdX1, dW0, db0, dW1, db1, ws, ws_bytes, B, d0, d1, c, S, s) != 0) { printf("dispatch refused\n"); exit(1); } };
+  } else if (bwd) {
     launch = [&] { if (emb::bwd_split_dispatch(dE, code, X0, X1, W0, W1, dX0, dX1, dW0, db0, dW1, db1, ws, ws_bytes, B, d0, d1, c, S, s) != 0) { printf("dispatch refused\n"); exit(1); } };
     int occ = 0;
     CK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, emb::embrace_bwd_split_kernel, emb::kBwdThreads, emb::kBwdLds));
@@ -115,8 +133,9 @@ int main(int argc, char** argv) {
     CK(hipMemset(dprof, 0, (size_t)max_blk * 16 * 8));
     launch(); CK(hipStreamSynchronize(s));
     static const char* const names[] = {"wgrad0", "wgrad1", "dgrad0", "dgrad1"};
+    static const char* const gnames[] = {"dgrad", "wgrad"};   // first tile of every persistent workgroup
     static const char* const fnames[] = {"fwd"};
-    report_stamps(dprof, max_blk, bwd ? names : fnames, bwd ? 4 : 1);
+    report_stamps(dprof, max_blk, gj ? gnames : (bwd ? names : fnames), gj ? 2 : (bwd ? 4 : 1));
   }
   return 0;
 }
