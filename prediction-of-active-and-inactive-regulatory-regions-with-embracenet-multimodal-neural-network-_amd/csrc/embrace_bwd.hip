@@ -224,7 +224,10 @@ extern "C" int emb_embrace_premask(const void* dE, const uint8_t* code, void* dD
 }
 
 extern "C" int emb_embrace_bwd_masked_supported(int B, int d0, int d1, int c, int dtype) {
-  return dtype == EMB_F32 && B > 0 && c % 4 == 0 && d0 % 4 == 0 && d1 % 4 == 0 && d0 > 0 && d1 > 0 && c > 0;
+  if (B <= 0 || c <= 0 || d0 <= 0 || d1 <= 0) return 0;
+  if (dtype == EMB_F32) return c % 4 == 0 && d0 % 4 == 0 && d1 % 4 == 0;      // ring GEMM (gemm_jobs.h)
+  if (dtype == EMB_BF16) return c % 16 == 0 && d0 % 8 == 0 && d1 % 8 == 0;   // split kernel without its mask stage (embrace_bwd_split.h)
+  return 0;
 }
 
 extern "C" int emb_embrace_bwd_masked(const void* dD0, const void* dD1, const void* X0, const void* X1, const void* W0,
@@ -235,7 +238,10 @@ extern "C" int emb_embrace_bwd_masked(const void* dD0, const void* dD1, const vo
   EMB_CHECK_ARG(emb_embrace_bwd_masked_supported(B, d0, d1, c, dtype),
                 "emb_embrace_bwd_masked: unsupported shape / dtype (see emb_embrace_bwd_masked_supported)");
   static const int force_S = [] { const char* e = getenv("EMB_BWD_S"); return e ? atoi(e) : 0; }();
-  const int rc = emb::gemm_jobs_bwd_dispatch(dD0, dD1, X0, X1, W0, W1, dX0, dX1, dW0, db0, dW1, db1, workspace, workspace_bytes, B,
+  const int rc = dtype == EMB_BF16
+                     ? emb::bwd_split_dispatch(nullptr, nullptr, dD0, dD1, X0, X1, W0, W1, dX0, dX1, dW0, db0, dW1, db1, workspace,
+                                               workspace_bytes, B, d0, d1, c, force_S, (hipStream_t)stream)
+                     : emb::gemm_jobs_bwd_dispatch(dD0, dD1, X0, X1, W0, W1, dX0, dX1, dW0, db0, dW1, db1, workspace, workspace_bytes, B,
                                              d0, d1, c, force_S, (hipStream_t)stream);
   if (rc == 1) {
     emb::set_error("emb_embrace_bwd_masked: operands must be 16-byte aligned and smaller than 2 GiB");
@@ -255,7 +261,7 @@ extern "C" int emb_embrace_bwd(const void* dE, const uint8_t* code, const void* 
     static const bool use_split = [] { const char* e = getenv("EMB_BWD_IMPL"); return !(e && strcmp(e, "tiled") == 0); }();
     static const int force_S = [] { const char* e = getenv("EMB_BWD_S"); return e ? atoi(e) : 0; }();
     if (use_split) {
-      const int rc = emb::bwd_split_dispatch(dE, code, X0, X1, W0, W1, dX0, dX1, dW0, db0, dW1, db1, workspace, workspace_bytes, B, d0, d1, c, force_S, s);
+      const int rc = emb::bwd_split_dispatch(dE, code, nullptr, nullptr, X0, X1, W0, W1, dX0, dX1, dW0, db0, dW1, db1, workspace, workspace_bytes, B, d0, d1, c, force_S, s);
       if (rc != 1) return rc;
     }
   }

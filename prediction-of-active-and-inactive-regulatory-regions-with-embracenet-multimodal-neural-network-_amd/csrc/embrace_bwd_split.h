@@ -30,6 +30,7 @@ typedef __attribute__((ext_vector_type(2))) int i32x2;
 typedef __attribute__((ext_vector_type(2))) unsigned int u32x2;
 
 struct SplitJob {
+  const __bf16* A;      // the gradient operand [B][c]: dE (masked from the code bytes per fragment), or the pre-masked dD_m
   const __bf16* Bptr;   // dgrad: W_m [c][d];  wgrad: X_m [B][d]
   void* C;              // dgrad: dX_m [B][d] bf16;  wgrad: dW_m [c][d] f32, or the slabs [S][c][pitch] when S > 1
   float* bias;          // wgrad, S == 1: db_m [c]
@@ -94,10 +95,10 @@ __device__ __forceinline__ bf16x8 km_frag_at(uint32_t a) {
 constexpr int kBwdThreads = 512;                  // 8 waves, two per SIMD: one wave's mask / address instructions overlap the other's MFMAs
 constexpr int kBwdBuf = 80 * 1024;                // one round: operand images + code bytes of 128 reduction indices
 constexpr int kBwdLds = 2 * kBwdBuf;
-constexpr int kBwdDmaPerRound = 10;               // LDS-DMA instructions a wave issues per round (both job kinds)
+template <bool MASKED> constexpr int kBwdDmaPerRound = MASKED ? 10 : 8;   // LDS-DMA instructions a wave issues per round (both job kinds); no code images for pre-masked gradients
 
-__device__ __forceinline__ void bwd_wait_round(bool next_in_flight) {
-  if (next_in_flight) EMB_WAIT_VMCNT(kBwdDmaPerRound);           // the younger round stays in flight
+template <bool MASKED> __device__ __forceinline__ void bwd_wait_round(bool next_in_flight) {
+  if (next_in_flight) EMB_WAIT_VMCNT(kBwdDmaPerRound<MASKED>);   // the younger round stays in flight
   else EMB_WAIT_VMCNT(0);
   __builtin_amdgcn_s_barrier();                                  // raw barrier: a __syncthreads() would drain the younger round
   asm volatile("" ::: "memory");
@@ -111,8 +112,9 @@ struct DgradStep {                                // fragments of one k-step (32
   bf16x8 a[4], braw[2];
   u32x2 cw[2];
 };
-__device__ __forceinline__ void dgrad_tile(const __bf16* __restrict__ dE, const uint8_t* __restrict__ code, int B, int c,
-                                           const SplitJob& job, int tile, char* smem) {
+template <bool MASKED>
+__device__ __forceinline__ void dgrad_tile(const uint8_t* __restrict__ code, int B, int c, const SplitJob& job, int tile, char* smem) {
+  const __bf16* __restrict__ dE = job.A;
   constexpr int DE_IMG = 128 * 128, CD_IMG = 128 * 64, W_IMG = 64 * 128;
   constexpr int CD_OFF = 2 * DE_IMG, W_OFF = CD_OFF + 2 * CD_IMG;
   static_assert(W_OFF + 4 * W_IMG == kBwdBuf, "dgrad buffer layout");
@@ -142,10 +144,10 @@ __device__ __forceinline__ void dgrad_tile(const __bf16* __restrict__ dE, const 
       const int k0 = rd * 128 + cc * 64;
       if (k0 + 64 <= c) {
         de.issue(dEo + k0 * 2, dma_nrec(de_bytes - k0 * 2), buf + cc * DE_IMG);
-        dc.issue(cdo + k0, dma_nrec(cd_bytes - k0), buf + CD_OFF + cc * CD_IMG);
+        if constexpr (MASKED) dc.issue(cdo + k0, dma_nrec(cd_bytes - k0), buf + CD_OFF + cc * CD_IMG);
       } else {                                                   // k beyond c reads zeros (not the next row)
         de.issue_tail(dEo + k0 * 2, dma_nrec(de_bytes - k0 * 2), (c - k0) * 2, buf + cc * DE_IMG);
-        dc.issue_tail(cdo + k0, dma_nrec(cd_bytes - k0), c - k0, buf + CD_OFF + cc * CD_IMG);
+        if constexpr (MASKED) dc.issue_tail(cdo + k0, dma_nrec(cd_bytes - k0), c - k0, buf + CD_OFF + cc * CD_IMG);
       }
       const uint32_t wrec = dma_nrec(w_bytes - (long)k0 * d * 2);
       dw[0].issue(Wo + (long)k0 * d * 2, wrec, buf + W_OFF + (2 * cc) * W_IMG);
@@ -178,7 +180,7 @@ __device__ __forceinline__ void dgrad_tile(const __bf16* __restrict__ dE, const 
 #pragma unroll
     for (int mi = 0; mi < 2; ++mi) {
       f.braw[mi] = lds_read16<__bf16>(dimg + mi * 2048);
-      f.cw[mi] = *(const lds_u2*)(uintptr_t)(cimg + mi * 1024);
+      if constexpr (MASKED) f.cw[mi] = *(const lds_u2*)(uintptr_t)(cimg + mi * 1024);
     }
   };
 
@@ -191,7 +193,7 @@ __device__ __forceinline__ void dgrad_tile(const __bf16* __restrict__ dE, const 
       for (int q = 0; q < 4; ++q) acc[ni][mi][q] = 0.0f;
 
   for (int rd = 0; rd < rounds; ++rd) {
-    bwd_wait_round(rd + 1 < rounds);
+    bwd_wait_round<MASKED>(rd + 1 < rounds);
     if (rd == 0) EMB_STAMP(4);
     const uint32_t buf = lds0 + (uint32_t)((rd & 1) * kBwdBuf);
     const int nsteps = min(4, (c - rd * 128 + 31) / 32);         // k-steps of this round that hold data
@@ -204,7 +206,8 @@ __device__ __forceinline__ void dgrad_tile(const __bf16* __restrict__ dE, const 
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int mi = 0; mi < 2; ++mi) {
-          const bf16x8 b = mask_frag(f[s & 1].braw[mi], f[s & 1].cw[mi][0], f[s & 1].cw[mi][1], sh);
+          bf16x8 b = f[s & 1].braw[mi];
+          if constexpr (MASKED) b = mask_frag(b, f[s & 1].cw[mi][0], f[s & 1].cw[mi][1], sh);
 #pragma unroll
           for (int ni = 0; ni < 4; ++ni) acc[ni][mi] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(f[s & 1].a[ni], b, acc[ni][mi], 0, 0, 0);
         }
@@ -256,8 +259,10 @@ struct WgradStep {                                // fragments of one chunk (32 
   bf16x8 a[4], braw[2];
   i32x2 cw[2];
 };
-__device__ __forceinline__ void wgrad_tile(const __bf16* __restrict__ dE, const uint8_t* __restrict__ code, int B, int c,
-                                           const SplitJob& job, int tile, int slice, char* smem) {
+template <bool MASKED>
+__device__ __forceinline__ void wgrad_tile(const uint8_t* __restrict__ code, int B, int c, const SplitJob& job, int tile, int slice,
+                                           char* smem) {
+  const __bf16* __restrict__ dE = job.A;
   constexpr int KB = 32;
   constexpr int DE_IMG = KB * 128, CD_IMG = KB * 64, X_IMG = KB * 128;
   constexpr int CD_OFF = 8 * DE_IMG, X_OFF = CD_OFF + 8 * CD_IMG;
@@ -285,7 +290,7 @@ __device__ __forceinline__ void wgrad_tile(const __bf16* __restrict__ dE, const 
     const uint32_t buf = lds0 + (uint32_t)((rd & 1) * kBwdBuf);
     const long r0 = k_begin + rd * 128 + qc * KB;                // rows >= k_end read zeros (range check on the slice end)
     de.issue(dEo + r0 * c * 2, dma_nrec(((long)k_end - r0) * c * 2), buf + (uint32_t)((2 * qc + qh) * DE_IMG));
-    dc.issue(cdo + r0 * c, dma_nrec(((long)k_end - r0) * c), buf + CD_OFF + (uint32_t)((2 * qc + qh) * CD_IMG));
+    if constexpr (MASKED) dc.issue(cdo + r0 * c, dma_nrec(((long)k_end - r0) * c), buf + CD_OFF + (uint32_t)((2 * qc + qh) * CD_IMG));
     dx.issue(Xo + r0 * d * 2, dma_nrec(((long)k_end - r0) * d * 2), buf + X_OFF + (uint32_t)((2 * qc + qh) * X_IMG));
   };
   const int rounds = (k_end - k_begin + 127) / 128;
@@ -323,7 +328,7 @@ __device__ __forceinline__ void wgrad_tile(const __bf16* __restrict__ dE, const 
 #pragma unroll
     for (int ci = 0; ci < 2; ++ci) {
       f.braw[ci] = km_frag_at(dimg + doff[ci]);
-      f.cw[ci] = __builtin_amdgcn_ds_read_tr8_b64_v2i32((lds_i32x2*)(uintptr_t)(cimg + ctr[ci]));
+      if constexpr (MASKED) f.cw[ci] = __builtin_amdgcn_ds_read_tr8_b64_v2i32((lds_i32x2*)(uintptr_t)(cimg + ctr[ci]));
     }
 #pragma unroll
     for (int ni = 0; ni < 4; ++ni) f.a[ni] = km_frag_at(ximg + koff[ni]);
@@ -341,7 +346,7 @@ __device__ __forceinline__ void wgrad_tile(const __bf16* __restrict__ dE, const 
   }
 
   for (int rd = 0; rd < rounds; ++rd) {
-    bwd_wait_round(rd + 1 < rounds);
+    bwd_wait_round<MASKED>(rd + 1 < rounds);
     if (rd == 0) EMB_STAMP(4);
     const uint32_t buf = lds0 + (uint32_t)((rd & 1) * kBwdBuf);
     const int nsteps = min(4, (k_end - k_begin - rd * 128 + KB - 1) / KB);   // chunks of this round that hold rows
@@ -354,7 +359,8 @@ __device__ __forceinline__ void wgrad_tile(const __bf16* __restrict__ dE, const 
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int ci = 0; ci < 2; ++ci) {
-          const bf16x8 b = mask_frag(f[s & 1].braw[ci], (uint32_t)f[s & 1].cw[ci][0], (uint32_t)f[s & 1].cw[ci][1], sh);
+          bf16x8 b = f[s & 1].braw[ci];
+          if constexpr (MASKED) b = mask_frag(b, (uint32_t)f[s & 1].cw[ci][0], (uint32_t)f[s & 1].cw[ci][1], sh);
 #pragma unroll
           for (int ni = 0; ni < 4; ++ni) acc[ci][ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(f[s & 1].a[ni], b, acc[ci][ni], 0, 0, 0);
           if (with_bias) accb[ci] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ones, b, accb[ci], 0, 0, 0);
@@ -410,14 +416,18 @@ __device__ __forceinline__ void wgrad_tile(const __bf16* __restrict__ dE, const 
 __device__ __forceinline__ SplitJob pick_job(int k, const SplitJob& a, const SplitJob& b, const SplitJob& c, const SplitJob& d) {
   SplitJob j;
 #define EMB_PICK(f) j.f = k == 0 ? a.f : (k == 1 ? b.f : (k == 2 ? c.f : d.f))
-  EMB_PICK(Bptr); EMB_PICK(C); EMB_PICK(bias); EMB_PICK(d); EMB_PICK(tiles_n); EMB_PICK(tiles); EMB_PICK(S); EMB_PICK(kper);
+  EMB_PICK(A); EMB_PICK(Bptr); EMB_PICK(C); EMB_PICK(bias); EMB_PICK(d); EMB_PICK(tiles_n); EMB_PICK(tiles); EMB_PICK(S); EMB_PICK(kper);
   EMB_PICK(pitch); EMB_PICK(end); EMB_PICK(mod); EMB_PICK(magic_a); EMB_PICK(magic_b);
 #undef EMB_PICK
   return j;
 }
 
-__global__ __launch_bounds__(kBwdThreads, 2) void embrace_bwd_split_kernel(const __bf16* __restrict__ dE, const uint8_t* __restrict__ code,
-                                                                      int B, int c, const SplitJob wg1, const SplitJob dg1,
+// MASKED: the gradient operand is dE and every fragment is masked from the forward's code bytes; !MASKED: the jobs' operands are
+// the pre-masked dD_m the producer of dE wrote (emb_head_ce_masked / emb_embrace_premask): no code images (a fifth of the staged
+// bytes, 8 instead of 10 LDS-DMA instructions per wave and round), no mask arithmetic (28 vector instructions per 8 MFMAs)
+template <bool MASKED>
+__global__ __launch_bounds__(kBwdThreads, 2) void embrace_bwd_split_kernel(const uint8_t* __restrict__ code, int B, int c,
+                                                                      const SplitJob wg1, const SplitJob dg1,
                                                                       const SplitJob wg0, const SplitJob dg0) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int bid = blockIdx.x;
@@ -426,23 +436,25 @@ __global__ __launch_bounds__(kBwdThreads, 2) void embrace_bwd_split_kernel(const
   const int first = kind == 0 ? 0 : (kind == 1 ? wg1.end : (kind == 2 ? dg1.end : wg0.end));
   const int q = bid - first;
   if (kind & 1) {
-    dgrad_tile(dE, code, B, c, job, kind == 1 ? xcd_remap(q, job.tiles) : q, smem);
+    dgrad_tile<MASKED>(code, B, c, job, kind == 1 ? xcd_remap(q, job.tiles) : q, smem);
   } else {
     const int slice = div_magic(q, job.magic_a), t = q - slice * job.tiles;
-    wgrad_tile(dE, code, B, c, job, kind == 0 ? xcd_remap(t, job.tiles) : t, slice, smem);
+    wgrad_tile<MASKED>(code, B, c, job, kind == 0 ? xcd_remap(t, job.tiles) : t, slice, smem);
   }
   EMB_STAMP(8);
 }
 
 // returns 1 when the shapes do not qualify (caller uses the tiled kernel of embrace_bwd.hip)
-static int bwd_split_dispatch(const void* dE, const uint8_t* code, const void* X0, const void* X1, const void* W0, const void* W1,
+// dD0 / dD1 != nullptr: the pre-masked gradients (dE and code are then not read)
+static int bwd_split_dispatch(const void* dE, const uint8_t* code, const void* dD0, const void* dD1, const void* X0, const void* X1, const void* W0, const void* W1,
                               void* dX0, void* dX1, void* dW0, void* db0, void* dW1, void* db1, void* ws, int64_t ws_bytes, int B,
                               int d0, int d1, int c, int force_S, hipStream_t s) {
   if (c % 16 || d0 % 8 || d1 % 8) return 1;
-  const void* ptrs[] = {dE, X0, X1, W0, W1, dX0, dX1, dW0, dW1};
+  const bool premasked = dD0 != nullptr && dD1 != nullptr;
+  const void* ptrs[] = {dE, dD0, dD1, X0, X1, W0, W1, dX0, dX1, dW0, dW1};
   for (const void* p : ptrs)
     if (p != nullptr && !aligned16(p)) return 1;
-  if ((reinterpret_cast<uintptr_t>(code) & 15u) != 0) return 1;
+  if (!premasked && (reinterpret_cast<uintptr_t>(code) & 15u) != 0) return 1;
   const long big = (long)B * (d1 > c ? d1 : c) * 2;
   if (big >= (1l << 31) || (long)c * d1 * 2 >= (1l << 31)) return 1;     // 32-bit buffer offsets (split_core.h)
   if ((long)cdiv(B, 128) * cdiv(d1, 128) >= 65536 || (long)cdiv(c, 128) * cdiv(d1, 128) * 16 >= 65536) return 1;   // div_magic range
@@ -451,6 +463,7 @@ static int bwd_split_dispatch(const void* dE, const uint8_t* code, const void* X
   struct SlabInfo { float* slab; int pitch; int S; } slabs[2] = {{nullptr, 0, 1}, {nullptr, 0, 1}};
   auto wgrad = [&](const void* X, void* dW, void* db, int d, int m) {
     SplitJob j{};
+    j.A = (const __bf16*)(premasked ? (m ? dD1 : dD0) : dE);
     j.Bptr = (const __bf16*)X; j.C = dW; j.bias = (float*)db; j.d = d;
     j.tiles_n = cdiv(d, 128);
     j.tiles = cdiv(c, 128) * j.tiles_n;
@@ -483,6 +496,7 @@ static int bwd_split_dispatch(const void* dE, const uint8_t* code, const void* X
   };
   auto dgrad = [&](const void* W, void* dX, int d, int m) {
     SplitJob j{};
+    j.A = (const __bf16*)(premasked ? (m ? dD1 : dD0) : dE);
     j.Bptr = (const __bf16*)W; j.C = dX; j.d = d;
     j.tiles_n = cdiv(d, 128);
     j.tiles = cdiv(B, 128) * j.tiles_n;
@@ -499,10 +513,12 @@ static int bwd_split_dispatch(const void* dE, const uint8_t* code, const void* X
   const SplitJob dg0 = dgrad(W0, dX0, d0, 0);
   static bool attr_set = false;
   if (!attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&embrace_bwd_split_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, kBwdLds);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&embrace_bwd_split_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, kBwdLds);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&embrace_bwd_split_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, kBwdLds);
     attr_set = true;
   }
-  embrace_bwd_split_kernel<<<n, kBwdThreads, kBwdLds, s>>>((const __bf16*)dE, code, B, c, wg1, dg1, wg0, dg0);
+  if (premasked) embrace_bwd_split_kernel<false><<<n, kBwdThreads, kBwdLds, s>>>(code, B, c, wg1, dg1, wg0, dg0);
+  else embrace_bwd_split_kernel<true><<<n, kBwdThreads, kBwdLds, s>>>(code, B, c, wg1, dg1, wg0, dg0);
   EMB_CHECK_LAUNCH();
   for (int m = 1; m >= 0; --m) {
     if (slabs[m].S > 1) {

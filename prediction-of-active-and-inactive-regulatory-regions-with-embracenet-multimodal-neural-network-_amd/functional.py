@@ -256,6 +256,8 @@ class _EmbraceFn(torch.autograd.Function):
         if pm is not None and not (pm[2] == code.data_ptr() and pm[0].shape == (B, c) and pm[0].dtype == T):
             pm = None
         ok = bool(L_.emb_embrace_bwd_masked_supported(B, d0, d1, c, DTYPE_CODE[T])) and (B * c) % 8 == 0
+        if pm is None and T != torch.float32:
+            ok = False                 # bf16: a separate mask launch costs more than the fragment masks of emb_embrace_bwd
         if ok and pm is None:          # another producer of dE (hidden post layers, a plain autograd loss): mask here, once
             pm = (torch.empty(B, c, dtype=T, device=dev), torch.empty(B, c, dtype=T, device=dev), code.data_ptr())
             check(L_.emb_embrace_premask(ptr(dE), ptr(code), ptr(pm[0]), ptr(pm[1]), B, c, DTYPE_CODE[T], stream()),

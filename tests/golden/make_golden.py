@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Generate the golden fixtures G1-G11 by importing the reference on CPU.
+"""Generate the golden fixtures G1-G13 by importing the reference on CPU.
 
 Runs ONLY in the build container (needs /root/reference).  The fixtures it writes under
 tests/golden/ are data (inputs are regenerated from oracle/datagen.py by name; outputs are

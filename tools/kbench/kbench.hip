@@ -84,7 +84,8 @@ static void report_stamps(unsigned long long* dprof, int nblk, const char* const
 int main(int argc, char** argv) {
   if (argc < 6) { printf("usage: kbench bwd|gj|fwd B d0 d1 c [S]\n"); return 1; }
   const bool gj = strcmp(argv[1], "gj") == 0;             // the persistent ring GEMM on pre-masked gradients (gemm_jobs.h)
-  const bool bwd = strcmp(argv[1], "bwd") == 0 || gj;
+  const bool pre = strcmp(argv[1], "bwdpre") == 0;        // the split kernel on pre-masked gradients (no mask stage)
+  const bool bwd = strcmp(argv[1], "bwd") == 0 || gj || pre;
   const int B = atoi(argv[2]), d0 = atoi(argv[3]), d1 = atoi(argv[4]), c = atoi(argv[5]), S = argc > 6 ? atoi(argv[6]) : 0;
   hipStream_t s; CK(hipStreamCreate(&s));
   __bf16* X0 = dev_random<__bf16>((size_t)B * d0, 1, 1.0f);
@@ -116,9 +117,9 @@ int main(int argc, char** argv) {
     CK(hipMalloc(&fdX0, (size_t)B * d0 * 4)); CK(hipMalloc(&fdX1, (size_t)B * d1 * 4));
     launch = [&] { if (emb::gemm_jobs_bwd_dispatch(fdE, fdE, fX0, fX1, fW0, fW1, fdX0, fdX1, dW0, db0, dW1, db1, ws, ws_bytes, B, d0, d1, c, S, s) != 0) { printf("dispatch refused\n"); exit(1); } };
   } else if (bwd) {
-    launch = [&] { if (emb::bwd_split_dispatch(dE, code, X0, X1, W0, W1, dX0, dX1, dW0, db0, dW1, db1, ws, ws_bytes, B, d0, d1, c, S, s) != 0) { printf("dispatch refused\n"); exit(1); } };
+    launch = [&] { if (emb::bwd_split_dispatch(dE, code, pre ? dE : nullptr, pre ? dE : nullptr, X0, X1, W0, W1, dX0, dX1, dW0, db0, dW1, db1, ws, ws_bytes, B, d0, d1, c, S, s) != 0) { printf("dispatch refused\n"); exit(1); } };
     int occ = 0;
-    CK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, emb::embrace_bwd_split_kernel, emb::kBwdThreads, emb::kBwdLds));
+    CK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, emb::embrace_bwd_split_kernel<true>, emb::kBwdThreads, emb::kBwdLds));
     printf("occupancy query (bwd): %d blocks/CU\n", occ);
   } else {
     launch = [&] { if (emb::fwd_split_dispatch<__bf16>(X0, X1, W0, b0, W1, b1, sel, nullptr, 7, 1, nullptr, 0, E, code, B, d0, d1, c, s) != 0) { printf("dispatch refused\n"); exit(1); } };
