@@ -585,10 +585,14 @@ def main():
     # pre-network bucket after the backward.  Two trailing slots of the second bucket carry the NEXT step's local
     # (positives, rows): the global class counts a step needs before its loss are thus reduced one step ahead
     # inside the gradient collective (labels are known when a batch is staged).
-    flat = D.BucketedFlatGrads(model, extra=2) if dist_path else None
-    local_counts = F.count_labels(y).to(torch.float32) if dist_path else None
-
     fused_loss = (not args.no_fused_loss) and model.fused_loss_ready(B)
+    # fused head: the count exchange needs no launches of its own -- the head reads the global counts from, and writes the
+    # shard's counts into, a four-float block that lives in the late gradient bucket (csrc/head.hip, global_counts = 2);
+    # one two-element copy after the all-reduce moves the sums into place for the next step
+    exch = dist_path and fused_loss
+    flat = D.BucketedFlatGrads(model, extra=4 if exch else 2) if dist_path else None
+    local_counts = F.count_labels(y).to(torch.float32) if (dist_path and not exch) else None
+
     overlap = {"early": True}   # first bucket's all-reduce issued from inside the backward (off when the backward is captured
                                 # in a graph that must not contain collectives)
 
@@ -596,7 +600,7 @@ def main():
         if flat is None:
             opt.zero_grad(set_to_none=True)
         if fused_loss:                                    # the head's launch takes the loss and its own backward along
-            model.arm_fused_loss(F.FusedLoss(y, counts, dist_path, loss_slot, conf_slot, ticks))
+            model.arm_fused_loss(F.FusedLoss(y, flat.extra if exch else counts, 2 if exch else dist_path, loss_slot, conf_slot, ticks))
         out = model([x1, x2], is_training=True)
         if fused_loss:
             dlogits = out.detach()                        # ignored by the head's node (the armed loss is the graph's root)
@@ -618,13 +622,20 @@ def main():
             F.reduce_flush()                              # (pre-network slabs)
 
     def reduce_grads():
+        if exch:
+            flat.finish()                                 # waits for the first bucket, reduces the second (+ the shards' counts)
+            F.cast(flat.extra[2:4], torch.float32, out=flat.extra[0:2])
+            return
         flat.extra.copy_(local_counts)                    # next batch's labels (synthetic: the same batch)
-        flat.finish()                                     # waits for the first bucket, reduces the second
+        flat.finish()
         counts.copy_(flat.extra.round().to(torch.int64))
 
     if dist_path:                                         # counts of the very first step
         F.count_labels(y, out=counts)
         D.allreduce_counts(counts)
+        if exch:
+            flat.extra.zero_()
+            flat.extra[0:2] = counts.to(torch.float32)
 
     def opt_step():
         opt.step()

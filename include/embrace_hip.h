@@ -355,7 +355,11 @@ int emb_head_ce_finish(const void* workspace, void* dW, void* db, float* loss, i
  * the PRE-MASKED gradients dD_m = dE * keep_m (keep_m = EMB_CODE_KEEP0 / KEEP1: selected modality and active ReLU) that
  * emb_embrace_bwd_masked multiplies -- the mask is applied once, by the kernel that produces dE, instead of per MFMA fragment
  * in the backward GEMMs.  code, dD0, dD1: all three or none (then identical to emb_head_ce).  dE may be NULL when only the
- * masked gradients are wanted. */
+ * masked gradients are wanted.
+ * global_counts (both entry points): 0 = count this batch's labels (class_counts int64[2] is written), 1 = class_counts holds
+ * the (positives, rows) of the GLOBAL batch, 2 = class_counts is a float[4] exchange block: [0..1] the global counts as floats
+ * (read), [2..3] receive this shard's own (positives, rows) -- a data-parallel trainer lets [2..3] ride in its gradient
+ * all-reduce and copies the sums to [0..1] for the next step (bench.py). */
 int emb_head_ce_masked(const void* E, const void* W, const void* bias, const int64_t* target, int64_t* class_counts,
                        int global_counts, void* logits, void* dE, const uint8_t* code, void* dD0, void* dD1, void* workspace,
                        int64_t workspace_bytes, uint64_t* tick_a, uint64_t* tick_b, int B, int K, int dtype, emb_stream_t stream);

@@ -100,7 +100,19 @@ template <typename T, int KS> __global__ __launch_bounds__(256) void head_ce_ker
   }
   __syncthreads();
   long long pos = (scount[0] + scount[1]) + (scount[2] + scount[3]), n = B;
-  if (a.global_counts) {
+  if (a.global_counts == 2) {
+    // data-parallel exchange block of FOUR floats: [0..1] = (positives, rows) of the GLOBAL batch, reduced one step ahead inside
+    // the gradient all-reduce; [2..3] receive this shard's own counts for the next reduction (bench.py: the slots ride in the
+    // late gradient bucket) -- no count kernel, no conversion launches around the collective
+    float* cf = reinterpret_cast<float*>(a.class_counts);
+    const long long lpos = pos;
+    pos = (long long)llrintf(cf[0]);
+    n = (long long)llrintf(cf[1]);
+    if (blockIdx.x == 0 && tid == 0) {
+      cf[2] = (float)lpos;
+      cf[3] = (float)B;
+    }
+  } else if (a.global_counts) {
     pos = a.class_counts[0];
     n = a.class_counts[1];
   } else if (blockIdx.x == 0 && tid == 0) {

@@ -5,6 +5,7 @@
 
 #include "reduce.h"
 #include "first_fin.h"
+#include "first_gram.h"
 #include "rider.h"
 
 namespace emb {
@@ -53,7 +54,25 @@ template <typename P> __device__ __forceinline__ void reduce_write(const ReduceJ
 }
 
 // block = (256 / lanes) elements x `lanes` slice lanes: lane sl sums slices sl, sl + lanes, ...; the lane sums meet in lane order
-template <typename P> __global__ __launch_bounds__(256) void multi_reduce_kernel(const ReduceTable tab) {
+// nfin > 0: the first `nfin` workgroups run the parked per-channel finish of the first conv block's recompute-free backward
+// (first_gram.h) -- in a data-parallel step the gradients must be complete before the all-reduce, so the finish cannot wait
+// for the optimizer launch, but it need not be a launch of its own either (9.4 us): it rides here
+struct FinStoreR {
+  const FirstFinArgs& a;
+  int c;
+  __device__ __forceinline__ void scalars(float dgamma, float dbeta, float dbias) const {
+    a.dgamma[c] = dgamma; a.dbeta[c] = dbeta; a.dbias[c] = dbias;
+  }
+  __device__ __forceinline__ void dw(long idx, float v) const { a.dW[idx] = v; }
+};
+template <typename P> __global__ __launch_bounds__(256) void multi_reduce_kernel(const ReduceTable tab, const FirstFinArgs fin, const int nfin) {
+  if constexpr (sizeof(P) == 4) {
+    if ((int)blockIdx.x < nfin) {
+      __shared__ float fin_lds[first_finish_lds_floats<256>()];
+      first_finish_body<256>(fin, (int)blockIdx.x, fin_lds, FinStoreR{fin, (int)blockIdx.x});
+      return;
+    }
+  }
   __shared__ ReduceTable t;
   __shared__ P red[4][256];
   {
@@ -63,9 +82,10 @@ template <typename P> __global__ __launch_bounds__(256) void multi_reduce_kernel
   }
   __syncthreads();
   int ji = 0;
-  while (ji < t.n - 1 && (int)blockIdx.x >= t.d[ji].blk_end) ++ji;
+  const int blk = (int)blockIdx.x - nfin;
+  while (ji < t.n - 1 && blk >= t.d[ji].blk_end) ++ji;
   const DevJob& d = t.d[ji];
-  const int bid = (int)blockIdx.x - (ji == 0 ? 0 : t.d[ji - 1].blk_end);
+  const int bid = blk - (ji == 0 ? 0 : t.d[ji - 1].blk_end);
   const int lanes = d.lanes, qpb = 256 / lanes, qi = threadIdx.x % qpb, sl = threadIdx.x / qpb;
   const long per = d.j.per;
   const P* in = (const P*)d.j.in;
@@ -130,7 +150,7 @@ static std::map<hipStream_t, Lot>& lots() {
 }
 #define EMB_LOT(var, stream) std::lock_guard<std::recursive_mutex> lot_guard__(emb::lot_mutex()); emb::Lot& var = emb::lots()[(stream)]
 
-template <typename P> static int launch_jobs(const ReduceJob* jobs, int n, hipStream_t s) {
+template <typename P> static int launch_jobs(const ReduceJob* jobs, int n, hipStream_t s, const FirstFinArgs* fin = nullptr) {
   for (int off = 0; off < n; off += kMaxJobs) {
     ReduceTable t{};
     const int cnt = n - off < kMaxJobs ? n - off : kMaxJobs;
@@ -146,8 +166,9 @@ template <typename P> static int launch_jobs(const ReduceJob* jobs, int n, hipSt
       t.d[i].blk_end = blocks;
     }
     t.n = cnt;
-    if (blocks == 0) continue;
-    multi_reduce_kernel<P><<<blocks, 256, 0, s>>>(t);
+    const int nfin = (fin != nullptr && off == 0) ? fin->C : 0;   // (rides on the first launch)
+    if (blocks + nfin == 0) continue;
+    multi_reduce_kernel<P><<<blocks + nfin, 256, 0, s>>>(t, nfin ? *fin : FirstFinArgs{}, nfin);
     EMB_CHECK_LAUNCH();
   }
   return EMB_OK;
@@ -302,9 +323,16 @@ extern "C" int emb_reduce_flush(emb_stream_t stream) {
   if (rc != EMB_OK) return rc;
   rc = emb::gram_jobs_flush(s);
   if (rc != EMB_OK) return rc;
-  rc = emb::first_fin_flush(s);
-  if (rc != EMB_OK) return rc;
-  if (!lot.f32.empty()) rc = emb::launch_jobs<float>(lot.f32.data(), (int)lot.f32.size(), s);
+  // a parked first-block finish rides on the f32 reduction launch when there is one (and it fits one launch's blocks)
+  const bool ride = lot.fin_valid && !lot.f32.empty() && lot.fin.C <= 1024;
+  if (!ride) {
+    rc = emb::first_fin_flush(s);
+    if (rc != EMB_OK) return rc;
+  }
+  if (!lot.f32.empty()) {
+    rc = emb::launch_jobs<float>(lot.f32.data(), (int)lot.f32.size(), s, ride ? &lot.fin : nullptr);
+    if (ride) lot.fin_valid = false;
+  }
   if (rc == EMB_OK && !lot.f64.empty()) rc = emb::launch_jobs<double>(lot.f64.data(), (int)lot.f64.size(), s);
   lot.f32.clear();
   lot.f64.clear();

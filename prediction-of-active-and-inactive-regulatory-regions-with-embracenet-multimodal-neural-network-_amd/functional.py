@@ -688,7 +688,9 @@ class FusedLoss:
     __slots__ = ("target", "class_counts", "global_counts", "loss_out", "confusion", "ticks")
 
     def __init__(self, target, class_counts, global_counts, loss_out, confusion, ticks=()):
-        self.target, self.class_counts, self.global_counts = target, class_counts, bool(global_counts)
+        # global_counts: False = count this batch's labels (class_counts int64[2] is filled), True = class_counts holds the
+        # GLOBAL (positives, rows), 2 = class_counts is the float32[4] data-parallel exchange block of csrc/head.hip
+        self.target, self.class_counts, self.global_counts = target, class_counts, int(global_counts)
         self.loss_out, self.confusion, self.ticks = loss_out, confusion, tuple(t for t in ticks if t is not None)
 
 
