@@ -13,6 +13,7 @@
 // finalised in double; BN + ReLU + max-pool (+ dropout) is one elementwise pass; the backward recomputes the
 // pooled gradient by a deterministic gather (no atomics anywhere: results are bitwise reproducible).
 #include "conv_direct.h"
+#include "gemm_jobs_api.h"
 #include "conv_first.h"
 #include "first_fin.h"
 #include "rider.h"
@@ -788,7 +789,13 @@ static int convblock_fwd(const void* x, const void* wpack, const void* bias, con
   }
   if (bn_phase != 2) {   // the convolution (stored) and its per-tile channel sums
     int tiles_m = conv_tiling(B, L, pad).tiles_m;
-    int rc = launch_conv_direct(dtype_code<T>(), true, x, wpack, bias, y, ws, &tiles_m, B, L, cin_pad, KK, Cout, pad, s);
+    int rc = 1;
+    if constexpr (sizeof(T) == 4)   // fp32: ring GEMM on the shifted activation rows (gemm_jobs.h); its row tiles are never more than the direct kernel's
+      rc = gemm_jobs_conv(true, x, wpack, bias, y, ws, &tiles_m, B, L, cin_pad, KK, Cout, pad, s);
+    if (rc == 1) {
+      tiles_m = conv_tiling(B, L, pad).tiles_m;
+      rc = launch_conv_direct(dtype_code<T>(), true, x, wpack, bias, y, ws, &tiles_m, B, L, cin_pad, KK, Cout, pad, s);
+    }
     if (rc == 1) {   // activation tile does not fit in LDS: generic GEMM on the im2col view
       if (Cout >= 64) rc = launch_conv_gemm<typename ConvCfg<T>::F64, true>(x, wpack, bias, y, ws, R, L, cin_pad, KK, Cout, pad, s);
       else rc = launch_conv_gemm<typename ConvCfg<T>::F32, true>(x, wpack, bias, y, ws, R, L, cin_pad, KK, Cout, pad, s);
@@ -975,6 +982,11 @@ static int convblock_bwd(const void* dout, int dout_ncl, const uint8_t* argmax, 
         dual = rc == EMB_OK;
       }
     }
+    if constexpr (sizeof(T) == 4) {
+      int S_ring = S;
+      rc = gemm_jobs_conv_wgrad(dy, x, slab, B, L, cin_pad, KK, Cout, pad, &S_ring, s);
+      if (rc == EMB_OK) S = S_ring;
+    }
     if (rc == 1) rc = launch_conv_wgrad_direct(dtype_code<T>(), dy, x, slab, B, L, cin_pad, KK, Cout, pad, S, s);
     if (rc == 1) {
       const int tiles_n = cdiv(KK + 1, CW::BN), tiles = cdiv(Cout, CW::BM) * tiles_n;
@@ -999,7 +1011,9 @@ static int convblock_bwd(const void* dout, int dout_ncl, const uint8_t* argmax, 
     if (rcr != EMB_OK) return rcr;
   }
   if (dx != nullptr && !dual) {   // dgrad: the same conv-view GEMM on dy with flipped taps
-    int rc = launch_conv_direct(dtype_code<T>(), false, dy, wflip, nullptr, dx, nullptr, nullptr, B, L, Cout, k * Cout, cin_pad, pad, s);
+    int rc = 1;
+    if constexpr (sizeof(T) == 4) rc = gemm_jobs_conv(false, dy, wflip, nullptr, dx, nullptr, nullptr, B, L, Cout, k * Cout, cin_pad, pad, s);
+    if (rc == 1) rc = launch_conv_direct(dtype_code<T>(), false, dy, wflip, nullptr, dx, nullptr, nullptr, B, L, Cout, k * Cout, cin_pad, pad, s);
     if (rc == 1) {
       if (cin_pad >= 64) rc = launch_conv_gemm<typename ConvCfg<T>::F64, false>(dy, wflip, nullptr, dx, nullptr, R, L, Cout, k * Cout, cin_pad, pad, s);
       else rc = launch_conv_gemm<typename ConvCfg<T>::F32, false>(dy, wflip, nullptr, dx, nullptr, R, L, Cout, k * Cout, cin_pad, pad, s);

@@ -13,7 +13,7 @@
 #include "gemm_tile.h"
 #include "reduce.h"
 #include "embrace_bwd_split.h"
-#include "gemm_jobs.h"
+#include "gemm_jobs_api.h"
 #include <cstdlib>
 #include <cstring>
 
@@ -241,7 +241,7 @@ extern "C" int emb_embrace_bwd_masked(const void* dD0, const void* dD1, const vo
   const int rc = dtype == EMB_BF16
                      ? emb::bwd_split_dispatch(nullptr, nullptr, dD0, dD1, X0, X1, W0, W1, dX0, dX1, dW0, db0, dW1, db1, workspace,
                                                workspace_bytes, B, d0, d1, c, force_S, (hipStream_t)stream)
-                     : emb::gemm_jobs_bwd_dispatch(dD0, dD1, X0, X1, W0, W1, dX0, dX1, dW0, db0, dW1, db1, workspace, workspace_bytes, B,
+                     : emb::gemm_jobs_bwd(dD0, dD1, X0, X1, W0, W1, dX0, dX1, dW0, db0, dW1, db1, workspace, workspace_bytes, B,
                                              d0, d1, c, force_S, (hipStream_t)stream);
   if (rc == 1) {
     emb::set_error("emb_embrace_bwd_masked: operands must be 16-byte aligned and smaller than 2 GiB");

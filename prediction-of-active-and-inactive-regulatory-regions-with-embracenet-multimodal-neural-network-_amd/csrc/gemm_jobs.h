@@ -27,6 +27,7 @@
 // MFMA step (h, j), h = 0..1, j = 0..3: lane group g supplies k = 16 h + 4 g + j on both operands -- the row-major operand
 // with ONE ds_read_b128 per (tile, h) (its four floats are the four j), the K-major operands with one ds_read_b32 per step.
 #pragma once
+#include "conv_tiles.h"
 #include "embrace_bwd_split.h"
 
 namespace emb {
@@ -50,7 +51,15 @@ struct GJob {
   int tiles_m, tiles_n, tiles;   // 128-wide tiles; tiles = tiles_m * tiles_n
   int S, kper;          // wgrad: the reduction is cut into S slices of kper rows
   int first, count;     // this job's range of the launch's tile list; count = tiles * S
-  int kind;             // 0 dgrad (A row-major), 1 wgrad (A K-major)
+  int kind;             // 0 dgrad (A row-major, Bm K-major), 1 wgrad (both K-major), 2 convolution forward / input gradient (A = activation
+                        // rows shifted by the tap, Bm = packed weights ROW-major [N][K]), 3 convolution weight gradient (A = dy K-major,
+                        // Bm = activation rows shifted per 32-column quarter)
+  // convolutions (kinds 2, 3; Conv1d of CNN_pre.py:37-38 on channels-last rows r = b * L + l): sequence length, channels of the
+  // shifted activation operand, left padding, rows B * L
+  int L, cin, pad, R;
+  int epi;              // epilogue: 0 store, 1 convolution forward (+ bias, per-tile BatchNorm partial sums), 2 slab + bias column (kind 3)
+  const float* bias_in; // epi 1: bias [N]
+  float* partial;       // epi 1: [tiles_m][2][N] sums of y and y^2 over the tile's rows
   int m_fast;           // tile order inside a slice: 1 = m tile fastest (tiles sharing an n-side panel are neighbours), 0 = n tile fastest
   uint32_t magic_tiles, magic_inner;   // ceil(2^32 / tiles), ceil(2^32 / (m_fast ? tiles_m : tiles_n))
 };
@@ -68,6 +77,9 @@ struct GTile {
   const char *A, *Bm;
   char* C;
   float* bias;
+  int L, cin, pad, R, epi, tm;
+  const float* bias_in;
+  float* partial;
 };
 
 // The job table is read through the kernel-argument segment POINTER with a run-time job index (scalar loads with a register
@@ -98,6 +110,8 @@ __device__ __forceinline__ GTile gj_decode(int id, gj_args_ptr ka) {
   t.A = j.A; t.Bm = j.Bm;
   t.C = j.C + (long)slice * j.slice_stride;
   t.bias = j.bias;
+  t.L = j.L; t.cin = j.cin; t.pad = j.pad; t.R = j.R; t.epi = j.epi; t.tm = tm;
+  t.bias_in = j.bias_in; t.partial = j.partial;
   return t;
 }
 
@@ -129,6 +143,13 @@ __device__ __forceinline__ void gj_dma(const gj_rsrc& rs_in, uint32_t lds, uint3
 }
 
 struct GFeed {
+  // convolution kinds: the tap and channel block of the stage being requested, channel blocks per tap, and per lane the position
+  // inside its sequence of this lane's rows (a shifted row outside [0, L) is the zero padding)
+  int tap, cb, cpt, L, pad, cin4;      // cin4 = bytes per activation row
+  int lpos[2];                          // kind 2: rows 8 wave + rl and + 64;  kind 3: [0] = the k row of this lane's instructions
+  uint32_t cbase[2];                    // kind 2: byte offset of the unshifted row;  kind 3: column part of quarter i (or invalid)
+  int qtap[2];                          // kind 3: tap of this wave's two quarters
+  int krow0;                            // kind 3: first activation row of the tile's slice + this lane's row in the instruction
   int valid, kind, stage, nstages, slot;
   int tail_rem;                    // dgrad: valid bytes of the m-side rows in the LAST stage (128 = whole window)
   gj_rsrc ra, rb;
@@ -158,6 +179,56 @@ __device__ __forceinline__ void gj_feed_tile(GFeed& f, const GTile& t, int lane,
     const int cb = t.n0 * 4 + 128 * q + kslot;
     f.off[2 + i] = cb < t.N * 4 ? krow * (uint32_t)(t.ldb * 4) + (uint32_t)cb : kDmaInvalid;
     f.dst[2 + i] = (uint32_t)(16384 + q * 4096 + (wave & 3) * 1024);
+  }
+  if (t.kind == 2) {
+    // forward / input gradient of a convolution: y[r][n] = sum_{tap, ci} x[r + tap - pad][ci] w[n][tap * cin + ci]; stage s = (tap,
+    // channel block of 32); A image = rows m0 .. m0 + 127 of x SHIFTED by tap - pad (zero outside the sequence), Bm image = 128
+    // rows of the packed weights [N][K], 32 reduction indices each
+    const uint32_t row = (uint32_t)(8 * wave + rl);
+    const int slot = 16 * ((lane & 7) ^ swz16((int)row));
+    f.ra = gj_make_rsrc(t.A, (long)t.R * t.cin * 4);
+    f.rb = gj_make_rsrc(t.Bm + (long)t.n0 * t.ldb * 4, (long)(t.N - t.n0) * t.ldb * 4);
+    f.tap = 0; f.cb = 0; f.cpt = t.cin / 32; f.L = t.L; f.pad = t.pad; f.cin4 = t.cin * 4;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int r = t.m0 + (int)row + 64 * i;
+      const int b = r / t.L;
+      f.lpos[i] = r < t.R ? r - b * t.L : -(1 << 24);
+      f.cbase[i] = (uint32_t)r * (uint32_t)(t.cin * 4) + (uint32_t)slot;
+      f.off[2 + i] = (row + 64u * i) * (uint32_t)(t.ldb * 4) + (uint32_t)slot;
+      f.dst[i] = (uint32_t)(i * 8192 + wave * 1024);
+      f.dst[2 + i] = (uint32_t)(16384 + i * 8192 + wave * 1024);
+    }
+    f.step_a = 0; f.step_b = 128u;
+    f.slot16 = 0; f.tail_rem = 128;
+    return;
+  }
+  if (t.kind == 3) {
+    // weight gradient of a convolution: dW[co][tap * cin + ci] = sum_r dy[r][co] x[r + tap - pad][ci]; A = dy K-major quarters
+    // as in kind 1; every 32-column quarter of the n side is one (tap, channel block): its rows are x shifted by tap - pad
+    const long a0 = (long)t.k_begin * t.lda * 4;
+    f.ra = gj_make_rsrc(t.A + a0, (long)klen * t.lda * 4);
+    f.step_a = (uint32_t)(kGjKC * t.lda * 4);
+    f.rb = gj_make_rsrc(t.Bm, (long)t.R * t.cin * 4);
+    f.step_b = 0;
+    f.L = t.L; f.pad = t.pad; f.cin4 = t.cin * 4;
+    f.krow0 = t.k_begin + (int)krow;
+    f.lpos[0] = f.krow0 % t.L;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int q = (wave >> 2) + 2 * i;
+      const int cbm = t.m0 * 4 + 128 * q + kslot;
+      f.off[i] = cbm < t.M * 4 ? krow * (uint32_t)(t.lda * 4) + (uint32_t)cbm : kDmaInvalid;
+      f.dst[i] = (uint32_t)(q * 4096 + (wave & 3) * 1024);
+      const int col = t.n0 + 32 * q;                         // first column of the quarter: (tap, channel block)
+      const int tq = col / t.cin;
+      f.qtap[i] = tq;
+      f.cbase[i] = col < t.N ? (uint32_t)((col - tq * t.cin) * 4 + kslot) : kDmaInvalid;
+      f.dst[2 + i] = (uint32_t)(16384 + q * 4096 + (wave & 3) * 1024);
+      f.off[2 + i] = 0;
+    }
+    f.slot16 = 0; f.tail_rem = 128;
+    return;
   }
   if (t.kind == 0) {                                              // A row-major: 128 m rows x 128 B of k; instructions wave, wave + 8
     const uint32_t row = (uint32_t)(8 * wave + rl);
@@ -194,6 +265,28 @@ __device__ __forceinline__ void gj_feed_tile(GFeed& f, const GTile& t, int lane,
 __device__ __forceinline__ bool gj_more(const GFeed& f) { return f.stage < f.nstages; }
 template <int I> __device__ __forceinline__ void gj_part(GFeed& f, uint32_t lds0) {
   const uint32_t buf = lds0 + (uint32_t)(f.slot * kGjStage) + f.dst[I];
+  if (f.kind == 2 && I < 2) {                      // activation rows shifted by the stage's tap
+    const int sh = f.tap - f.pad;
+    const bool ok = (unsigned)(f.lpos[I] + sh) < (unsigned)f.L;
+    gj_dma(f.ra, buf, ok ? f.cbase[I] + (uint32_t)(sh * f.cin4 + f.cb * 128) : kDmaInvalid);
+    if (I == 1) { if (++f.cb == f.cpt) { f.cb = 0; ++f.tap; } }
+    return;
+  }
+  if (f.kind == 3 && I >= 2) {                     // activation rows shifted by the quarter's tap
+    const int sh = f.qtap[I - 2] - f.pad;
+    const bool ok = f.cbase[I - 2] != kDmaInvalid && (unsigned)(f.lpos[0] + sh) < (unsigned)f.L;
+    const int r = f.krow0 + f.stage * kGjKC + sh;
+    gj_dma(f.rb, buf, ok ? (uint32_t)r * (uint32_t)f.cin4 + f.cbase[I - 2] : kDmaInvalid);
+    if (I == 3) {
+      int l = f.lpos[0] + kGjKC;                   // position of the next stage's row inside its sequence (L >= 16)
+      if (l >= f.L) l -= f.L;
+      if (l >= f.L) l -= f.L;
+      f.lpos[0] = l;
+      f.slot = f.slot + 1 == kGjSlots ? 0 : f.slot + 1;
+      ++f.stage;
+    }
+    return;
+  }
   if (I < 2) {
     uint32_t o = f.off[I];
     if (f.kind == 0 && f.stage + 1 == f.nstages && f.tail_rem < 128 && f.slot16 >= f.tail_rem) o = kDmaInvalid;   // k beyond K reads zeros
@@ -278,17 +371,27 @@ __global__ __launch_bounds__(kGjThreads, 2) void gemm_jobs_kernel(const GArgs ar
   // fragments of half h of the stage in `buf`.  The slot base is added to the four lane parts ONCE per call; everything else
   // of an address is a compile-time constant and travels in the instruction's offset field (one address add per read otherwise)
   auto load = [&](uint32_t buf, int kind, int h, GHalf& x) {
-    uint32_t nb[2][2];
+    if (kind == 2) {                                 // packed weights, row-major image of 128 n rows: one 16-byte read per tile
+      const uint32_t nbr = rmo[h] + (buf + (uint32_t)(16384 + wc * 64 * 128));
 #pragma unroll
-    for (int u = 0; u < 2; ++u)
+      for (int ni = 0; ni < 4; ++ni) {
+        const f32x4 v = lds_read16<float>(nbr + ni * 2048);
 #pragma unroll
-      for (int jj = 0; jj < 2; ++jj) nb[u][jj] = kmo[u][jj] + (buf + n_img);
+        for (int j = 0; j < 4; ++j) x.a[ni][j] = v[j];
+      }
+    } else {
+      uint32_t nb[2][2];
 #pragma unroll
-    for (int ni = 0; ni < 4; ++ni)
+      for (int u = 0; u < 2; ++u)
 #pragma unroll
-      for (int j = 0; j < 4; ++j)
-        x.a[ni][j] = *(lds_f32*)(uintptr_t)(nb[ni & 1][j >> 1] + (uint32_t)((ni >> 1) * 4096 + (16 * h + j) * 128));
-    if (kind == 0) {
+        for (int jj = 0; jj < 2; ++jj) nb[u][jj] = kmo[u][jj] + (buf + n_img);
+#pragma unroll
+      for (int ni = 0; ni < 4; ++ni)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+          x.a[ni][j] = *(lds_f32*)(uintptr_t)(nb[ni & 1][j >> 1] + (uint32_t)((ni >> 1) * 4096 + (16 * h + j) * 128));
+    }
+    if (kind == 0 || kind == 2) {
       const uint32_t ab = rmo[h] + (buf + ar_img);
 #pragma unroll
       for (int mi = 0; mi < 2; ++mi) {
@@ -327,7 +430,7 @@ __global__ __launch_bounds__(kGjThreads, 2) void gemm_jobs_kernel(const GArgs ar
       for (int ni = 0; ni < 4; ++ni)
 #pragma unroll
         for (int q = 0; q < 4; ++q) acc[ni][mi][q] = 0.0f;
-    const bool with_bias = t.kind == 1 && t.n0 == 0 && wc == 0;
+    const bool with_bias = (t.kind == 1 || t.kind == 3) && t.n0 == 0 && wc == 0;
     EMB_STAMP_KIND(t.kind);
     // waves w and w + 4 share a SIMD: the second half issues each DMA instruction one MFMA group EARLIER than its partner, so
     // that one of the two is multiplying while the other sits in the ~150 cycles an LDS-DMA instruction takes to issue
@@ -378,6 +481,52 @@ __global__ __launch_bounds__(kGjThreads, 2) void gemm_jobs_kernel(const GArgs ar
       const long rem = (((long)t.M - t.m0) * t.ldc - t.n0) * 4;                   // rows >= M are dropped by the range check
       const __amdgpu_buffer_rsrc_t rs =
           __builtin_amdgcn_make_buffer_rsrc((void*)(t.C + ((long)t.m0 * t.ldc + t.n0) * 4), 0, dma_nrec(rem), 0x00020000);
+      if (t.epi == 1) {
+        // convolution forward: + bias, and this tile's BatchNorm partial sums (sum y, sum y^2 per channel over its valid rows):
+        // per lane over its two row tiles, over the 16 rows of a lane group by DPP, over the four wave rows through LDS
+        float s1[4][4], s2[4][4];
+#pragma unroll
+        for (int ni = 0; ni < 4; ++ni) {
+          const int ncol = t.n0 + wc * 64 + ni * 16 + 4 * g;
+          f32x4 bv = {0.f, 0.f, 0.f, 0.f};
+          if (ncol < t.N) bv = *reinterpret_cast<const f32x4*>(t.bias_in + ncol);
+#pragma unroll
+          for (int q = 0; q < 4; ++q) { s1[ni][q] = 0.f; s2[ni][q] = 0.f; }
+#pragma unroll
+          for (int mi = 0; mi < 2; ++mi) {
+            const bool rv = t.m0 + wr * 32 + mi * 16 + r < t.M;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+              const float y = acc[ni][mi][q] + bv[q];
+              acc[ni][mi][q] = y;
+              s1[ni][q] += rv ? y : 0.f;
+              s2[ni][q] += rv ? y * y : 0.f;
+            }
+          }
+#pragma unroll
+          for (int q = 0; q < 4; ++q) { s1[ni][q] = row16_sum<float>(s1[ni][q]); s2[ni][q] = row16_sum<float>(s2[ni][q]); }
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();                                             // every stage has been multiplied: the ring is free
+        float* red = reinterpret_cast<float*>(smem);                              // [4 wave rows][2][128 channels]
+        if (r == 0) {
+#pragma unroll
+          for (int ni = 0; ni < 4; ++ni)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+              const int ch = wc * 64 + ni * 16 + 4 * g + q;
+              red[(wr * 2 + 0) * 128 + ch] = s1[ni][q];
+              red[(wr * 2 + 1) * 128 + ch] = s2[ni][q];
+            }
+        }
+        __syncthreads();
+        if (threadIdx.x < 256) {
+          const int which = threadIdx.x >> 7, ch = threadIdx.x & 127;
+          if (t.n0 + ch < t.N)
+            t.partial[((long)t.tm * 2 + which) * t.N + t.n0 + ch] =
+                ((red[(0 * 2 + which) * 128 + ch] + red[(1 * 2 + which) * 128 + ch]) + red[(2 * 2 + which) * 128 + ch]) + red[(3 * 2 + which) * 128 + ch];
+        }
+      }
 #pragma unroll
       for (int mi = 0; mi < 2; ++mi) {
         const uint32_t rowoff = (uint32_t)(wr * 32 + mi * 16 + r) * (uint32_t)t.ldc;
@@ -397,7 +546,7 @@ __global__ __launch_bounds__(kGjThreads, 2) void gemm_jobs_kernel(const GArgs ar
           sum += __shfl_xor(sum, 32, 64);
           const int crow = t.m0 + wr * 32 + mi * 16 + r;
           if (g == 0 && crow < t.M) {
-            if (t.S > 1) reinterpret_cast<float*>(t.C)[(long)crow * t.ldc + t.N] = sum;
+            if (t.S > 1 || t.epi == 2) reinterpret_cast<float*>(t.C)[(long)crow * t.ldc + t.N] = sum;
             else t.bias[crow] = sum;
           }
         }
@@ -409,7 +558,7 @@ __global__ __launch_bounds__(kGjThreads, 2) void gemm_jobs_kernel(const GArgs ar
 }
 
 // returns 1 when the shapes do not qualify (the caller keeps its other kernels)
-static int gemm_jobs_bwd_dispatch(const void* dD0, const void* dD1, const void* X0, const void* X1, const void* W0, const void* W1,
+static int gemm_jobs_bwd_impl(const void* dD0, const void* dD1, const void* X0, const void* X1, const void* W0, const void* W1,
                                   void* dX0, void* dX1, void* dW0, void* db0, void* dW1, void* db1, void* ws, int64_t ws_bytes, int B,
                                   int d0, int d1, int c, int force_S, hipStream_t s) {
   if (c % 4 || d0 % 4 || d1 % 4) return 1;
@@ -509,6 +658,76 @@ static int gemm_jobs_bwd_dispatch(const void* dD0, const void* dD1, const void* 
       if (rc != EMB_OK) return rc;
     }
   }
+  return EMB_OK;
+}
+
+// ---- fp32 convolutions of the stored-activation blocks as ring GEMM jobs (csrc/convblock.hip dispatches here) ---------------------
+static void gj_attr() {
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_jobs_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, kGjLds);
+    attr_set = true;
+  }
+}
+static bool gj_conv_ok(int B, int L, int cin, int N, int KK) {
+  const long R = (long)B * L;
+  // N >= 128: a 128-wide tile on fewer output channels leaves whole waves idle (measured at 64: slower than conv_direct.hip)
+  return cin % 32 == 0 && KK % 32 == 0 && N % 4 == 0 && N >= 128 && L >= 16 && R * (cin > N ? cin : N) * 4 < (1l << 31) &&
+         (long)N * KK * 4 < (1l << 31) && (R / 128 + 1) * (N / 128 + 1) < 65536;
+}
+// y[R][N] = conv(x[R][cin], w[N][KK]) (+ bias, + partial[tiles_m][2][N] when fwd); returns 1 when the shapes do not qualify.
+// The input gradient of a block is the same job on dy with the tap-flipped packed weights.
+static int gemm_jobs_conv_impl(bool fwd, const void* x, const void* w, const void* bias, void* out, void* partial, int* partial_rows, int B,
+                          int L, int cin, int KK, int N, int pad, hipStream_t s) {
+  if (!gj_conv_ok(B, L, cin, N, KK) || !aligned16(x) || !aligned16(w) || !aligned16(out) || (fwd && !aligned16(bias))) return 1;
+  const int R = B * L;
+  GJob j{};
+  j.A = (const char*)x; j.Bm = (const char*)w; j.C = (char*)out;
+  j.M = R; j.N = N; j.K = KK; j.lda = cin; j.ldb = KK; j.ldc = N;
+  j.tiles_m = cdiv(R, 128); j.tiles_n = cdiv(N, 128); j.tiles = j.tiles_m * j.tiles_n;
+  j.S = 1; j.kper = KK; j.kind = 2; j.m_fast = 0;   // n tile fastest: the tiles of one row block (they share the activation rows) are neighbours
+  j.first = 0; j.count = j.tiles;
+  j.magic_tiles = make_magic(j.tiles);
+  j.magic_inner = make_magic(j.tiles_n);
+  j.L = L; j.cin = cin; j.pad = pad; j.R = R;
+  j.epi = fwd ? 1 : 0; j.bias_in = (const float*)bias; j.partial = (float*)partial;
+  GArgs ga{};
+  ga.j[0] = j;
+  for (int a = 1; a < 4; ++a) { ga.j[a] = GJob{}; ga.j[a].first = j.count; }
+  ga.total = j.count;
+  gj_attr();
+  gemm_jobs_kernel<<<j.count, kGjThreads, kGjLds, s>>>(ga);
+  EMB_CHECK_LAUNCH();
+  if (partial_rows != nullptr) *partial_rows = j.tiles_m;
+  return EMB_OK;
+}
+// slab[S][Cout][KK + 1]: per-slice partial weight gradients (column KK = the bias gradient), S slices over the B * L rows
+// (*S_io: at most that many slices -- the slab's capacity; receives the number written)
+static int gemm_jobs_conv_wgrad_impl(const void* dy, const void* x, void* slab, int B, int L, int cin, int KK, int Cout, int pad, int* S_io,
+                                     hipStream_t s) {
+  int S = *S_io;
+  if (!gj_conv_ok(B, L, cin, Cout, KK) || KK < 64 || !aligned16(dy) || !aligned16(x) || !aligned16(slab) || S < 1) return 1;
+  const int R = B * L;
+  while (S > 1 && cdiv(R, cdiv(cdiv(R, S), kGjKC) * kGjKC) != S) --S;   // slices of whole stages that cover the rows exactly S times
+  *S_io = S;
+  GJob j{};
+  j.A = (const char*)dy; j.Bm = (const char*)x; j.C = (char*)slab;
+  j.M = Cout; j.N = KK; j.K = R; j.lda = Cout; j.ldb = cin; j.ldc = KK + 1;
+  j.tiles_m = cdiv(Cout, 128); j.tiles_n = cdiv(KK, 128); j.tiles = j.tiles_m * j.tiles_n;
+  j.kper = cdiv(cdiv(R, S), kGjKC) * kGjKC;
+  j.S = S; j.slice_stride = (long)Cout * (KK + 1) * 4;
+  j.kind = 3; j.m_fast = 1;
+  j.first = 0; j.count = j.tiles * S;
+  j.magic_tiles = make_magic(j.tiles);
+  j.magic_inner = make_magic(j.tiles_m);
+  j.L = L; j.cin = cin; j.pad = pad; j.R = R; j.epi = 2;
+  GArgs ga{};
+  ga.j[0] = j;
+  for (int a = 1; a < 4; ++a) { ga.j[a] = GJob{}; ga.j[a].first = j.count; }
+  ga.total = j.count;
+  gj_attr();
+  gemm_jobs_kernel<<<j.count, kGjThreads, kGjLds, s>>>(ga);
+  EMB_CHECK_LAUNCH();
   return EMB_OK;
 }
 

@@ -115,7 +115,7 @@ int main(int argc, char** argv) {
     fW0 = dev_random<float>((size_t)c * d0, 3, 0.1f); fW1 = dev_random<float>((size_t)c * d1, 4, 0.02f);
     fdE = dev_random<float>((size_t)B * c, 5, 1.0f);
     CK(hipMalloc(&fdX0, (size_t)B * d0 * 4)); CK(hipMalloc(&fdX1, (size_t)B * d1 * 4));
-    launch = [&] { if (emb::gemm_jobs_bwd_dispatch(fdE, fdE, fX0, fX1, fW0, fW1, fdX0, fdX1, dW0, db0, dW1, db1, ws, ws_bytes, B, d0, d1, c, S, s) != 0) { printf("dispatch refused\n"); exit(1); } };
+    launch = [&] { if (emb::gemm_jobs_bwd_impl(fdE, fdE, fX0, fX1, fW0, fW1, fdX0, fdX1, dW0, db0, dW1, db1, ws, ws_bytes, B, d0, d1, c, S, s) != 0) { printf("dispatch refused\n"); exit(1); } };
   } else if (bwd) {
     launch = [&] { if (emb::bwd_split_dispatch(dE, code, pre ? dE : nullptr, pre ? dE : nullptr, X0, X1, W0, W1, dX0, dX1, dW0, db0, dW1, db1, ws, ws_bytes, B, d0, d1, c, S, s) != 0) { printf("dispatch refused\n"); exit(1); } };
     int occ = 0;
