@@ -93,8 +93,13 @@ __device__ __forceinline__ bf16x8 km_frag_at(uint32_t a) {
 }
 
 constexpr int kBwdThreads = 512;                  // 8 waves, two per SIMD: one wave's mask / address instructions overlap the other's MFMAs
-constexpr int kBwdBuf = 80 * 1024;                // one round: operand images + code bytes of 128 reduction indices
-constexpr int kBwdLds = 2 * kBwdBuf;
+// one round = the operand images (+ code bytes when the fragments are masked in the kernel) of 128 reduction indices.  NBUF = 2:
+// round r + 1 lands while round r is multiplied, one workgroup per CU (the latency-bound single-wave-of-workgroups shapes:
+// B <= 1024).  NBUF = 1 (pre-masked operands only): 68 KB per workgroup, TWO workgroups per CU -- with several waves of workgroups
+// per CU (B = 4096) the second workgroup's loads, multiplies and stores fill the first one's set-up / wait / store phases.
+template <bool MASKED> constexpr int kBwdBuf = MASKED ? 80 * 1024 : 64 * 1024;
+constexpr int kBwdStageMin = 128 * 528 + 2048;    // the f32 weight-gradient tile staged for its row-segment stores
+template <bool MASKED, int NBUF> constexpr int kBwdLds = NBUF * kBwdBuf<MASKED> > kBwdStageMin ? NBUF * kBwdBuf<MASKED> : kBwdStageMin;
 template <bool MASKED> constexpr int kBwdDmaPerRound = MASKED ? 10 : 8;   // LDS-DMA instructions a wave issues per round (both job kinds); no code images for pre-masked gradients
 
 template <bool MASKED> __device__ __forceinline__ void bwd_wait_round(bool next_in_flight) {
@@ -112,12 +117,12 @@ struct DgradStep {                                // fragments of one k-step (32
   bf16x8 a[4], braw[2];
   u32x2 cw[2];
 };
-template <bool MASKED>
+template <bool MASKED, int NBUF>
 __device__ __forceinline__ void dgrad_tile(const uint8_t* __restrict__ code, int B, int c, const SplitJob& job, int tile, char* smem) {
   const __bf16* __restrict__ dE = job.A;
-  constexpr int DE_IMG = 128 * 128, CD_IMG = 128 * 64, W_IMG = 64 * 128;
+  constexpr int DE_IMG = 128 * 128, CD_IMG = MASKED ? 128 * 64 : 0, W_IMG = 64 * 128;
   constexpr int CD_OFF = 2 * DE_IMG, W_OFF = CD_OFF + 2 * CD_IMG;
-  static_assert(W_OFF + 4 * W_IMG == kBwdBuf, "dgrad buffer layout");
+  static_assert(W_OFF + 4 * W_IMG == kBwdBuf<MASKED>, "dgrad buffer layout");
   EMB_STAMP(2);
   EMB_STAMP_KIND(2 + job.mod);
   const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -138,7 +143,7 @@ __device__ __forceinline__ void dgrad_tile(const uint8_t* __restrict__ code, int
   dw[0].init((uint32_t)d * 2, n0 * 2, d * 2, lane, wave);        // columns >= d read zeros
   dw[1].init((uint32_t)d * 2, n0 * 2 + 128, d * 2, lane, wave);
   auto request = [&](int rd) {                                   // round rd: k range [128 rd, 128 rd + 128)
-    const uint32_t buf = lds0 + (uint32_t)((rd & 1) * kBwdBuf);
+    const uint32_t buf = lds0 + (uint32_t)((rd % NBUF) * kBwdBuf<MASKED>);
 #pragma unroll
     for (int cc = 0; cc < 2; ++cc) {
       const int k0 = rd * 128 + cc * 64;
@@ -156,7 +161,7 @@ __device__ __forceinline__ void dgrad_tile(const uint8_t* __restrict__ code, int
   };
   const int rounds = (c + 127) / 128;
   request(0);
-  if (rounds > 1) request(1);
+  if (NBUF > 1 && rounds > 1) request(1);
   EMB_STAMP(3);
 
   const RmLane rl = rm_lane(lane);
@@ -193,9 +198,9 @@ __device__ __forceinline__ void dgrad_tile(const uint8_t* __restrict__ code, int
       for (int q = 0; q < 4; ++q) acc[ni][mi][q] = 0.0f;
 
   for (int rd = 0; rd < rounds; ++rd) {
-    bwd_wait_round<MASKED>(rd + 1 < rounds);
+    bwd_wait_round<MASKED>(NBUF > 1 && rd + 1 < rounds);
     if (rd == 0) EMB_STAMP(4);
-    const uint32_t buf = lds0 + (uint32_t)((rd & 1) * kBwdBuf);
+    const uint32_t buf = lds0 + (uint32_t)((rd % NBUF) * kBwdBuf<MASKED>);
     const int nsteps = min(4, (c - rd * 128 + 31) / 32);         // k-steps of this round that hold data
     DgradStep f[2];
     load(buf, 0, f[0]);
@@ -214,10 +219,10 @@ __device__ __forceinline__ void dgrad_tile(const uint8_t* __restrict__ code, int
         __builtin_amdgcn_sched_barrier(0);
       }
     }
-    if (rd + 2 < rounds) {
+    if (rd + NBUF < rounds) {
       asm volatile("" ::: "memory");
       __builtin_amdgcn_s_barrier();                              // every wave has read this buffer
-      request(rd + 2);
+      request(rd + NBUF);
     }
   }
   EMB_STAMP(5);
@@ -259,14 +264,14 @@ struct WgradStep {                                // fragments of one chunk (32 
   bf16x8 a[4], braw[2];
   i32x2 cw[2];
 };
-template <bool MASKED>
+template <bool MASKED, int NBUF>
 __device__ __forceinline__ void wgrad_tile(const uint8_t* __restrict__ code, int B, int c, const SplitJob& job, int tile, int slice,
                                            char* smem) {
   const __bf16* __restrict__ dE = job.A;
   constexpr int KB = 32;
-  constexpr int DE_IMG = KB * 128, CD_IMG = KB * 64, X_IMG = KB * 128;
+  constexpr int DE_IMG = KB * 128, CD_IMG = MASKED ? KB * 64 : 0, X_IMG = KB * 128;
   constexpr int CD_OFF = 8 * DE_IMG, X_OFF = CD_OFF + 8 * CD_IMG;
-  static_assert(X_OFF + 8 * X_IMG == kBwdBuf, "wgrad buffer layout");
+  static_assert(X_OFF + 8 * X_IMG == kBwdBuf<MASKED>, "wgrad buffer layout");
   EMB_STAMP(2);
   EMB_STAMP_KIND(job.mod);
   const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -287,7 +292,7 @@ __device__ __forceinline__ void wgrad_tile(const uint8_t* __restrict__ code, int
   dc.init((uint32_t)c, c0 + 64 * qh, c, lane);
   dx.init((uint32_t)d * 2, (n0 + 64 * qh) * 2, d * 2, lane);
   auto request = [&](int rd) {
-    const uint32_t buf = lds0 + (uint32_t)((rd & 1) * kBwdBuf);
+    const uint32_t buf = lds0 + (uint32_t)((rd % NBUF) * kBwdBuf<MASKED>);
     const long r0 = k_begin + rd * 128 + qc * KB;                // rows >= k_end read zeros (range check on the slice end)
     de.issue(dEo + r0 * c * 2, dma_nrec(((long)k_end - r0) * c * 2), buf + (uint32_t)((2 * qc + qh) * DE_IMG));
     if constexpr (MASKED) dc.issue(cdo + r0 * c, dma_nrec(((long)k_end - r0) * c), buf + CD_OFF + (uint32_t)((2 * qc + qh) * CD_IMG));
@@ -295,7 +300,7 @@ __device__ __forceinline__ void wgrad_tile(const uint8_t* __restrict__ code, int
   };
   const int rounds = (k_end - k_begin + 127) / 128;
   request(0);
-  if (rounds > 1) request(1);
+  if (NBUF > 1 && rounds > 1) request(1);
   EMB_STAMP(3);
   const bool with_bias = (n0 == 0) && (wn == 0);
 
@@ -346,9 +351,9 @@ __device__ __forceinline__ void wgrad_tile(const uint8_t* __restrict__ code, int
   }
 
   for (int rd = 0; rd < rounds; ++rd) {
-    bwd_wait_round<MASKED>(rd + 1 < rounds);
+    bwd_wait_round<MASKED>(NBUF > 1 && rd + 1 < rounds);
     if (rd == 0) EMB_STAMP(4);
-    const uint32_t buf = lds0 + (uint32_t)((rd & 1) * kBwdBuf);
+    const uint32_t buf = lds0 + (uint32_t)((rd % NBUF) * kBwdBuf<MASKED>);
     const int nsteps = min(4, (k_end - k_begin - rd * 128 + KB - 1) / KB);   // chunks of this round that hold rows
     WgradStep f[2];
     load(buf, 0, f[0]);
@@ -368,10 +373,10 @@ __device__ __forceinline__ void wgrad_tile(const uint8_t* __restrict__ code, int
         __builtin_amdgcn_sched_barrier(0);
       }
     }
-    if (rd + 2 < rounds) {
+    if (rd + NBUF < rounds) {
       asm volatile("" ::: "memory");
       __builtin_amdgcn_s_barrier();
-      request(rd + 2);
+      request(rd + NBUF);
     }
   }
   EMB_STAMP(5);
@@ -425,8 +430,8 @@ __device__ __forceinline__ SplitJob pick_job(int k, const SplitJob& a, const Spl
 // MASKED: the gradient operand is dE and every fragment is masked from the forward's code bytes; !MASKED: the jobs' operands are
 // the pre-masked dD_m the producer of dE wrote (emb_head_ce_masked / emb_embrace_premask): no code images (a fifth of the staged
 // bytes, 8 instead of 10 LDS-DMA instructions per wave and round), no mask arithmetic (28 vector instructions per 8 MFMAs)
-template <bool MASKED>
-__global__ __launch_bounds__(kBwdThreads, 2) void embrace_bwd_split_kernel(const uint8_t* __restrict__ code, int B, int c,
+template <bool MASKED, int NBUF>
+__global__ __launch_bounds__(kBwdThreads, NBUF == 1 ? 4 : 2) void embrace_bwd_split_kernel(const uint8_t* __restrict__ code, int B, int c,
                                                                       const SplitJob wg1, const SplitJob dg1,
                                                                       const SplitJob wg0, const SplitJob dg0) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -436,10 +441,10 @@ __global__ __launch_bounds__(kBwdThreads, 2) void embrace_bwd_split_kernel(const
   const int first = kind == 0 ? 0 : (kind == 1 ? wg1.end : (kind == 2 ? dg1.end : wg0.end));
   const int q = bid - first;
   if (kind & 1) {
-    dgrad_tile<MASKED>(code, B, c, job, kind == 1 ? xcd_remap(q, job.tiles) : q, smem);
+    dgrad_tile<MASKED, NBUF>(code, B, c, job, kind == 1 ? xcd_remap(q, job.tiles) : q, smem);
   } else {
     const int slice = div_magic(q, job.magic_a), t = q - slice * job.tiles;
-    wgrad_tile<MASKED>(code, B, c, job, kind == 0 ? xcd_remap(t, job.tiles) : t, slice, smem);
+    wgrad_tile<MASKED, NBUF>(code, B, c, job, kind == 0 ? xcd_remap(t, job.tiles) : t, slice, smem);
   }
   EMB_STAMP(8);
 }
@@ -513,12 +518,19 @@ static int bwd_split_dispatch(const void* dE, const uint8_t* code, const void* d
   const SplitJob dg0 = dgrad(W0, dX0, d0, 0);
   static bool attr_set = false;
   if (!attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&embrace_bwd_split_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, kBwdLds);
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&embrace_bwd_split_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, kBwdLds);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&embrace_bwd_split_kernel<true, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, kBwdLds<true, 2>);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&embrace_bwd_split_kernel<false, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, kBwdLds<false, 2>);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&embrace_bwd_split_kernel<false, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, kBwdLds<false, 1>);
     attr_set = true;
   }
-  if (premasked) embrace_bwd_split_kernel<false><<<n, kBwdThreads, kBwdLds, s>>>(code, B, c, wg1, dg1, wg0, dg0);
-  else embrace_bwd_split_kernel<true><<<n, kBwdThreads, kBwdLds, s>>>(code, B, c, wg1, dg1, wg0, dg0);
+  static const int cus = [] {
+    int dev = 0, v = 0;
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || v <= 0) return 256;
+    return v;
+  }();
+  if (premasked && n >= cus + cus / 2) embrace_bwd_split_kernel<false, 1><<<n, kBwdThreads, kBwdLds<false, 1>, s>>>(code, B, c, wg1, dg1, wg0, dg0);
+  else if (premasked) embrace_bwd_split_kernel<false, 2><<<n, kBwdThreads, kBwdLds<false, 2>, s>>>(code, B, c, wg1, dg1, wg0, dg0);
+  else embrace_bwd_split_kernel<true, 2><<<n, kBwdThreads, kBwdLds<true, 2>, s>>>(code, B, c, wg1, dg1, wg0, dg0);
   EMB_CHECK_LAUNCH();
   for (int m = 1; m >= 0; --m) {
     if (slabs[m].S > 1) {

@@ -119,7 +119,7 @@ int main(int argc, char** argv) {
   } else if (bwd) {
     launch = [&] { if (emb::bwd_split_dispatch(dE, code, pre ? dE : nullptr, pre ? dE : nullptr, X0, X1, W0, W1, dX0, dX1, dW0, db0, dW1, db1, ws, ws_bytes, B, d0, d1, c, S, s) != 0) { printf("dispatch refused\n"); exit(1); } };
     int occ = 0;
-    CK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, emb::embrace_bwd_split_kernel<true>, emb::kBwdThreads, emb::kBwdLds));
+    CK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, emb::embrace_bwd_split_kernel<true, 2>, emb::kBwdThreads, emb::kBwdLds<true, 2>));
     printf("occupancy query (bwd): %d blocks/CU\n", occ);
   } else {
     launch = [&] { if (emb::fwd_split_dispatch<__bf16>(X0, X1, W0, b0, W1, b1, sel, nullptr, 7, 1, nullptr, 0, E, code, B, d0, d1, c, s) != 0) { printf("dispatch refused\n"); exit(1); } };
