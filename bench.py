@@ -431,13 +431,17 @@ def harness_rate(ea, wl, device, epochs=8):
 
 
 def step_accounting(wl, dims, ms_per_step, stats_csv, traffic_csv=None):
-    """Algorithmic FLOPs / HBM bytes (SURVEY 8d formulas, per launch = per step at this batch) of every kernel class of the
-    training step, next to the per-kernel average durations of the committed rocprofv3 --kernel-trace --stats summary of
-    this command (profiles/, same binary), and the whole-step line from the live ms_per_step.  Elementwise / pooling
-    kernels are priced by bytes, contractions by both; `frac` is against the roof that binds (bf16: 2.5 PFLOP/s, 8 TB/s)."""
+    """Algorithmic FLOPs / HBM bytes (SURVEY 8d formulas, per step at this batch) of every kernel class of the training step,
+    next to the time the class takes per step in the committed rocprofv3 --kernel-trace --stats summary of this command
+    (profiles/, same binary: sum over the class's kernels of Calls x AverageNs, divided by the profiled steps), and the
+    whole-step line from the live ms_per_step.  A class may be several launches (all stored-activation conv blocks of a deep
+    stack, the three small linear layers ...); `launches` says how many per step.  Elementwise / pooling kernels are priced by
+    bytes, contractions by both; `frac` is against the roof that binds for the precision (bf16: 2.5 PFLOP/s, fp32: 157.3
+    TFLOP/s, fp64: 78.6; HBM 8 TB/s)."""
     import csv
     hp, B = wl["hp"], wl["B"]
     s = {"bfloat16": 2, "float32": 4, "float64": 8}[wl["dtype"]]
+    bf = wl["dtype"] == "bfloat16"
     peak_tf, peak_gbs = MFMA_PEAK_TFLOPS[wl["dtype"]], HBM_PEAK_GBS
     d0, d1, c = dims
     # conv geometry (CNN_pre.py:24-60): L 256 -> 124 -> 58 -> 25 -> 8
@@ -448,68 +452,98 @@ def step_accounting(wl, dims, ms_per_step, stats_csv, traffic_csv=None):
         convs.append(dict(cin=cin, cout=co, k=k, L=L, Lp=Lp, flops=2.0 * cin * co * k * L * B,
                           x=B * L * max(cin, 8) * s, y=B * L * co * s, pooled=B * Lp * co * s, arg=B * Lp * co))
         cin, L = co, Lp
-    ffnn = sum(2.0 * a * b for a, b in zip([wl["F"]] + [hp[f"FFNN_n_units_l{i}"] for i in range(hp["FFNN_n_layers"] - 1)],
-                                           [hp[f"FFNN_n_units_l{i}"] for i in range(hp["FFNN_n_layers"])])) * B
+    ffw = [wl["F"]] + [hp[f"FFNN_n_units_l{i}"] for i in range(hp["FFNN_n_layers"])]
+    ffnn = sum(2.0 * a * b_ for a, b_ in zip(ffw[:-1], ffw[1:])) * B
+    pw = [c] + [hp[f"EMBRACENET_n_units_l{i}"] for i in range(hp["n_post_layers"])]
+    post = sum(2.0 * a * b_ for a, b_ in zip(pw[:-1], pw[1:])) * B          # hidden post layers (the head is its own class)
     K = d0 + d1
-    c0 = convs[0]
-    # kernel class -> (name fragments of the kernels that implement it, newest first; flops; bytes).  The epigenomic MLP stack
-    # has no launch of its own on the bf16 path: its forward / backward ride on first_stats / bn_bwd_dz (csrc/rider.h), whose
-    # lines therefore carry the MLP's FLOPs and bytes as well.
-    rider = wl["dtype"] == "bfloat16"
-    mlp_f, mlp_b = (ffnn, B * wl["F"] * s), (2 * ffnn, B * wl["F"] * s)
-    table = {
-        "first_stats": (["first_stats_rider_kernel", "first_kernel<2, 2, 0>"], c0["flops"] + (mlp_f[0] if rider else 0),
-                        B * 4 * 256 * s + c0["x"] + (mlp_f[1] if rider else 0)),                # loader layout in, image out
-        "first_apply": (["first_kernel<2, 2, 1>"], c0["flops"], c0["x"] + c0["pooled"] + c0["arg"]),   # recompute + BN/ReLU/pool out
-        # the recompute-free backward of block 1 (csrc/first_gram.h): ONE pass A = g^T xview (the weight-gradient contraction, no
-        # convolution) -- its per-channel finish runs inside the optimizer launch.  EMB_FIRST_LINEAR=0: the two recomputing passes.
-        "first_bwd_acc": (["first_kernel<2, 2, 4>"], c0["flops"], c0["x"] + c0["pooled"] + c0["arg"]),
-        "first_bwd_sums": (["first_kernel<2, 2, 2>"], c0["flops"], c0["x"] + c0["pooled"] + c0["arg"]),   # recompute + window-space sums
-        "first_bwd_wgrad": (["first_kernel<2, 2, 3>"], 2 * c0["flops"], c0["x"] + c0["pooled"] + c0["arg"]),   # recompute + weight gradient
-        "embrace_fwd": (["embrace_fwd"], 2.0 * B * c * K, s * B * K + s * c * K + s * B * c + B * c),
-        "embrace_bwd": (["embrace_bwd"], 4.0 * B * c * K, s * B * c + B * c + 2 * s * B * K + s * c * K + 4 * c * K),
-        "head_ce": (["head_ce"], 3 * 2.0 * B * c * 2, 2 * s * B * c),
-    }
-    if not rider:
-        table.update({"mlp_fwd": (["mlp_fwd"], *mlp_f), "mlp_bwd": (["mlp_bwd"], *mlp_b)})
-    if len(convs) > 1:
-        c1 = convs[1]
+    c0, rest = convs[0], convs[1:]
+    emb_f = (2.0 * B * c * K, s * B * K + s * c * K + s * B * c + B * c)
+    emb_b = (4.0 * B * c * K, s * B * c + B * c + 2 * s * B * K + s * c * K + 4 * c * K)
+    rider = bf      # bf16: the epigenomic MLP rides on first_stats / bn_bwd_dz (csrc/rider.h), whose lines carry its work
+    # class -> (kernel-name fragments, flops per step, bytes per step)
+    table = {}
+    if bf:
         table.update({
-            "conv2_fwd": (["conv_t_stream_kernel<2, 2, true", "conv_t_kernelIDF16bLi2"], c1["flops"], c1["x"] + c1["y"]),
-            "conv2_dgrad": (["conv_t_stream_kernel<4, 1, false", "conv_t_kernelIDF16bLi4"], c1["flops"], c1["y"] + c1["x"]),
-            "conv2_wgrad": (["conv_wgrad_stream", "conv_wgrad_direct"], c1["flops"], c1["y"] + c1["x"]),
-            "bn_relu_pool": (["bn_relu_pool"], 0.0, c1["y"] + c1["pooled"] + c1["arg"]),
-            "bn_bwd_dz": (["bn_bwd_dz"], (mlp_b[0] if rider else 0.0), c1["pooled"] + c1["arg"] + 2 * c1["y"] + (mlp_b[1] if rider else 0)),
-            "bn_bwd_affine": (["bn_bwd_affine"], 0.0, 3 * c1["y"]),
+            "first_stats": (["first_stats_rider_kernel", "first_kernel<2, 2, 0>"], c0["flops"] + ffnn, B * 4 * 256 * s + c0["x"] + B * wl["F"] * s),
+            "first_apply": (["first_kernel<2, 2, 1>"], c0["flops"], c0["x"] + c0["pooled"] + c0["arg"]),
+            "first_bwd_acc": (["first_kernel<2, 2, 4>"], c0["flops"], c0["x"] + c0["pooled"] + c0["arg"]),
+            "first_bwd_sums": (["first_kernel<2, 2, 2>"], c0["flops"], c0["x"] + c0["pooled"] + c0["arg"]),
+            "first_bwd_wgrad": (["first_kernel<2, 2, 3>"], 2 * c0["flops"], c0["x"] + c0["pooled"] + c0["arg"]),
         })
-    rows = {}
+        if len(convs) > 1:
+            c1 = convs[1]
+            table.update({
+                "conv2_fwd": (["conv_t_stream_kernel<2, 2, true", "conv_t_stream_kernel<4, 2, true", "conv_t_kernelIDF16bLi2"], c1["flops"], c1["x"] + c1["y"]),
+                "conv2_dgrad": (["conv_t_stream_kernel<4, 1, false", "conv_t_kernelIDF16bLi4"], c1["flops"], c1["y"] + c1["x"]),
+                "conv2_wgrad": (["conv_wgrad_stream", "conv_wgrad_direct"], c1["flops"], c1["y"] + c1["x"]),
+                "conv2_wgrad+dgrad": (["conv_bwd_dual_kernel"], 2 * c1["flops"], 2 * (c1["y"] + c1["x"])),
+            })
+    else:
+        # fp32 / fp64: block 1 and the stored-activation blocks run the same kernel families; all convolution launches of the
+        # step are ONE class (forward + input gradient of blocks >= 2 + weight gradient of every block), the ring GEMM launches
+        # (csrc/gemm_jobs.h) carry the fusion layer's backward as well
+        conv_fl = 3.0 * sum(cv["flops"] for cv in convs) - c0["flops"]
+        conv_by = sum(3 * (cv["x"] + cv["y"]) for cv in convs)
+        table["convolutions (all blocks: fwd, dgrad, wgrad)"] = (["conv_t_kernel<", "conv_direct_kernel<", "conv_wgrad_direct_kernel<", "conv_gemm_kernel",
+                                                                  "conv_wgrad_kernel<", "first_kernel<"], conv_fl, conv_by)
+        table["ring GEMM (conv blocks with >= 128 channels + fusion backward)"] = (["gemm_jobs_kernel"], 0.0, 0)   # priced below
+    table.update({
+        "embrace_fwd": (["embrace_fwd"], *emb_f),
+        "embrace_bwd": (["embrace_bwd"], *emb_b),
+        "head_ce": (["head_ce"], 3 * 2.0 * B * pw[-1] * 2, 2 * s * B * pw[-1]),
+        "bn_relu_pool": (["bn_relu_pool"], 0.0, sum(cv["y"] + cv["pooled"] + cv["arg"] for cv in (rest if bf else convs))),
+        "bn_bwd_dz": (["bn_bwd_dz"], (2 * ffnn if rider else 0.0), sum(cv["pooled"] + cv["arg"] + 2 * cv["y"] for cv in (rest if bf else convs)) + (B * wl["F"] * s if rider else 0)),
+        "bn_bwd_affine": (["bn_bwd_affine"], 0.0, sum(3 * cv["y"] for cv in (rest if bf else convs))),
+        "optimizer (+ slab sums)": (["multi_opt_kernel"], 0.0, 0),
+    })
+    if not rider:
+        table["mlp / linear layers (epigenomic stack, hidden post layers)"] = (["mlp_fwd", "mlp_bwd", "linear_fwd_kernel", "linear_bwd_kernel"],
+                                                                            3 * (ffnn + post), 3 * B * (wl["F"] + c) * s)
+    elif post:
+        table["hidden post layers"] = (["mlp_fwd", "mlp_bwd", "linear_fwd_kernel", "linear_bwd_kernel"], 3 * post, 3 * B * c * s)
+    rows, steps = {}, 1.0
     if stats_csv and os.path.exists(stats_csv):
         for r in csv.DictReader(open(stats_csv)):
-            rows[r["Name"]] = float(r["AverageNs"]) / 1e3
-    if any("conv_bwd_dual_kernel" in n for n in rows) and "conv2_wgrad" in table:   # one launch for both gradients of block 2
-        (_, f1, b1), (_, f2, b2) = table.pop("conv2_wgrad"), table.pop("conv2_dgrad")
-        table["conv2_wgrad+dgrad"] = (["conv_bwd_dual_kernel"], f1 + f2, b1 + b2)
-    if rows:   # classes whose kernels did not run in this step (the other first-block backward)
-        table = {cls: v for cls, v in table.items() if not cls.startswith("first_bwd") or any(f in n for f in v[0] for n in rows)}
+            rows[r["Name"]] = (float(r["Calls"]), float(r["AverageNs"]) / 1e3)
+        once = [v[0] for n, v in rows.items() if "multi_opt_kernel" in n or "head_ce_kernel" in n or "weighted_ce" in n]
+        steps = max(1.0, min(once)) if once else 1.0
+    if rows and not bf:
+        # the ring GEMM launches: the fusion backward (its class is then empty) plus the conv jobs they took over
+        ring = [n for n in rows if "gemm_jobs_kernel" in n]
+        if ring:
+            ring_conv = sum(cv["flops"] * (2 if (cv["cin"] % 32 == 0 and cv["cout"] >= 128) else 0) for cv in rest)      # forward + weight gradient
+            ring_conv += sum(cv["flops"] for cv in rest if cv["cout"] % 32 == 0 and cv["cin"] >= 128)                    # input gradient
+            name = "ring GEMM (conv blocks with >= 128 channels + fusion backward)"
+            table[name] = (["gemm_jobs_kernel"], ring_conv + emb_b[0], emb_b[1] + sum(2 * (cv["x"] + cv["y"]) for cv in rest if cv["cout"] >= 128))
+            cname = "convolutions (all blocks: fwd, dgrad, wgrad)"
+            f_, fl, by = table[cname]
+            table[cname] = (f_, fl - ring_conv, by)
+            table.pop("embrace_bwd", None) if not any("embrace_bwd" in n for n in rows) else None
+        else:
+            table.pop("ring GEMM (conv blocks with >= 128 channels + fusion backward)", None)
+    if rows:   # classes whose kernels did not run in this step
+        table = {cls: v for cls, v in table.items() if any(f in n for f in v[0] for n in rows)}
     hbm = {}    # kernel name -> HBM bytes per launch from the committed PMC passes of this command (tools/run_pmc_hbm.sh)
     if traffic_csv and os.path.exists(traffic_csv):
         for r in csv.DictReader(open(traffic_csv)):
             hbm[r["kernel"]] = float(r["hbm_MB_per_launch"]) * 1e6
     kernels = {}
     for cls, (frags, fl, by) in table.items():
-        us = next((v for f in frags for n, v in rows.items() if f in n), None)
-        ent = dict(algorithmic_flops=fl, algorithmic_bytes=by, us_per_launch=us)
-        tr = next((v for f in frags for n, v in hbm.items() if f in n), None)
-        if tr is not None:
-            ent.update(traffic=tr, traffic_over_algorithmic=tr / by)
-        if us:
+        hit = [(n, v) for n, v in rows.items() if any(f in n for f in frags)]
+        us = sum(calls * avg for _, (calls, avg) in hit) / steps if hit else None
+        ent = dict(algorithmic_flops=fl, algorithmic_bytes=by, us_per_step=us, launches=round(sum(c_ for _, (c_, _a) in hit) / steps, 2) if hit else None)
+        tr = [v for f in frags for n, v in hbm.items() if f in n]
+        if tr and by:
+            ent.update(traffic=sum(tr), traffic_over_algorithmic=sum(tr) / by)
+        if us and (fl or by):
             tf, gbs = fl / us / 1e6, by / us / 1e3
             ent.update(tflops=tf, gbs=gbs, frac=max(tf / peak_tf, gbs / peak_gbs), bound="mfma" if tf / peak_tf >= gbs / peak_gbs else "hbm")
         kernels[cls] = ent
-    total_fl = 3.0 * (sum(cv["flops"] for cv in convs) + ffnn + 2.0 * B * c * K + 2.0 * B * c * 2)
+    total_fl = 3.0 * (sum(cv["flops"] for cv in convs) + ffnn + post + 2.0 * B * c * K + 2.0 * B * pw[-1] * 2)
     total_by = sum(by for _, _, by in table.values())
     us_step = ms_per_step * 1e3
-    return dict(kernels=kernels, source=os.path.basename(stats_csv) if rows else None,
+    return dict(kernels=kernels, source=os.path.basename(stats_csv) if rows else None, profiled_steps=steps if rows else None,
                 traffic_source=os.path.basename(traffic_csv) if hbm else None,
                 whole_step=dict(algorithmic_flops=total_fl, algorithmic_bytes=total_by, us=us_step, tflops=total_fl / us_step / 1e6,
                                 gbs=total_by / us_step / 1e3, frac_mfma=total_fl / us_step / 1e6 / peak_tf,

@@ -301,7 +301,7 @@ int emb_convblock_needs_y(int B, int L, int cin_pad, int Cout, int k, int dtype)
  * (csrc/first_gram.h: the first block's convolution is linear in its weights, so the BatchNorm backward is assembled from
  * A = g^T xview, the input's lag statistics and the weights instead of re-running the convolution twice). */
 int64_t emb_convblock_stats_elems(int B, int L, int cin_pad, int Cout, int k, int dtype);
-/* The recompute-free backward of the fused first block (on by default; environment EMB_FIRST_LINEAR=0 turns it off): on != 0 /
+/* The recompute-free backward of the fused first block (on by default): on != 0 /
  * on == 0 switches it for the following emb_convblock_fwd + emb_convblock_bwd PAIRS (the backward needs what its forward left in
  * `stats`), on < 0 only asks.  Returns the previous setting.  In a deferring step (emb_reduce_defer) that backward parks its
  * per-channel finish until the optimizer launch (emb_*_step_multi holding the block's weight, gamma and beta gradients) or

@@ -434,7 +434,7 @@ static int launch_conv_t(const void* x, const void* w, const void* bias, void* o
   if (!aligned16(x) || !aligned16(w) || !aligned16(out) || KK % VEC || cin % VEC || (sizeof(T) == 2 && KK % 8)) return 1;
   const bool wreg = cdiv(KK, KSTEP) <= kWRegSteps && MT * kWRegSteps * (int)(sizeof(typename Mma<T>::Frag) / 4) <= 64;
   if constexpr (sizeof(T) == 2) {   // bf16: operands streamed by LDS-DMA (conv_t_stream.h)
-    static const bool stream_on = [] { const char* e = getenv("EMB_CONVT_IMPL"); return !(e && e[0] == 't'); }();   // "tiled": this file's kernel
+    constexpr bool stream_on = true;
     if (!wreg && stream_on) {
       const int rows = launch_conv_t_stream<MT, FWD>(x, w, bias, out, partial, B, L, cin, KK, N, pad, s);
       if (rows < 0) return rows;
@@ -697,7 +697,7 @@ template <typename T> static int wgrad_slices_t(int B, int L, int pad, int KK, i
 }
 
 static bool wgrad_stream_enabled() {
-  static const bool on = [] { const char* e = getenv("EMB_WGRAD_IMPL"); return !(e && e[0] == 'd'); }();   // "direct": the tiled kernel
+  constexpr bool on = true;
   return on;
 }
 
@@ -748,7 +748,7 @@ __global__ __launch_bounds__(512, 2) void conv_bwd_dual_kernel(const WsArgs wa, 
 // returns EMB_OK when the dual launch ran, 1 when the shapes / pointers do not qualify (the caller launches the two kernels)
 int launch_conv_bwd_dual(const void* dy, const void* x, void* slab, const void* wflip, void* dx, int B, int L, int cin, int k, int Cout,
                          int pad, int S, hipStream_t s) {
-  static const bool on = [] { const char* e = getenv("EMB_CONV_DUAL"); return !(e && e[0] == '0'); }();
+  constexpr bool on = true;
   const int KK = k * cin, KKd = k * Cout;
   if (!on || !wgrad_stream_enabled() || cin != 64 || !conv_wgrad_stream_shape_ok(B, L, cin, KK, Cout, pad) || !aligned16(dy) || !aligned16(x) ||
       !aligned16(wflip) || !aligned16(dx) || S > conv_tiling(B, L, pad).tiles_m)

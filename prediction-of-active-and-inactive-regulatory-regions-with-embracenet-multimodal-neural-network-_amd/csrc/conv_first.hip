@@ -969,7 +969,7 @@ int conv_first_apply(const void* x, int x_codes, const void* w, const void* bias
   if (fin != nullptr) a.fin_f = *fin;
   a.gram_part = const_cast<float*>(gram_part); a.gram_tot = gram_tot; a.gram_rows = gm.nblk;
   a.gram_edge = gram_part ? reinterpret_cast<__bf16*>(const_cast<float*>(gram_part) + (size_t)gm.nblk * kGramPart) : nullptr;
-  static const bool park = [] { const char* e = getenv("EMB_GRAM_PARK"); return !(e && e[0] == '0'); }();
+  constexpr bool park = true;
   if (gram_tot != nullptr && gram_part != nullptr && park) {   // the totals jobs leave this launch's prologue (first_fin.h)
     GramJobsArgs j{};
     j.edge = a.gram_edge; j.part = gram_part; j.tot = gram_tot; j.B = B; j.L = L; j.rows = gm.nblk; j.parts = Cout == 64 ? 2 : 1;

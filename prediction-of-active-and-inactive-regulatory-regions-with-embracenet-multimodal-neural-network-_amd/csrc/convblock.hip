@@ -714,14 +714,8 @@ template <typename T> static ConvWs conv_workspace(int B, int L, int cin_pad, in
 }
 
 // the recompute-free backward of the fused first block (first_gram.h) needs the forward to leave the lag statistics behind `stats`
-static int g_first_linear = -1;   // -1: not decided yet (environment EMB_FIRST_LINEAR=0 turns it off); emb_convblock_first_linear() sets it
-static bool first_linear_enabled() {
-  if (g_first_linear < 0) {
-    const char* e = getenv("EMB_FIRST_LINEAR");
-    g_first_linear = !(e && e[0] == '0');
-  }
-  return g_first_linear != 0;
-}
+static int g_first_linear = 1;    // emb_convblock_first_linear() switches it (the tests compare the two backward forms)
+static bool first_linear_enabled() { return g_first_linear != 0; }
 template <typename T> static bool first_linear(int training, int bn_phase) {
   return sizeof(T) == 2 && first_linear_enabled() && training && bn_phase == 0;
 }
@@ -763,7 +757,7 @@ static int convblock_fwd(const void* x, const void* wpack, const void* bias, con
       return EMB_OK;
     }
     // local statistics in training: the apply pass finalises them itself from the statistics pass's partial rows (bn_inline.h)
-    static const bool inline_fin = [] { const char* e = getenv("EMB_BN_INLINE"); return !(e && e[0] == '0'); }();
+    constexpr bool inline_fin = true;
     BnFinFwd fin{};
     bool inl = false;
     if constexpr (sizeof(P) == 4) {
@@ -808,7 +802,7 @@ static int convblock_fwd(const void* x, const void* wpack, const void* bias, con
       return EMB_OK;
     }
     if constexpr (sizeof(T) == 2) {   // bf16, local statistics: the pooling pass finalises them itself (bn_inline.h)
-      static const bool inline_fin = [] { const char* e = getenv("EMB_BN_INLINE"); return !(e && e[0] == '0'); }();
+      constexpr bool inline_fin = true;
       if (inline_fin && training && tiles_m > 0 && tiles_m <= 512 && Cout <= kBnInlineMaxC && Cout % 8 == 0) {
         BnFinFwd fin{};
         fin.partial = (const float*)ws; fin.rows = tiles_m; fin.gamma = (const float*)gamma; fin.beta = (const float*)beta;
@@ -873,7 +867,7 @@ static int convblock_bwd(const void* dout, int dout_ncl, const uint8_t* argmax, 
       if (rc != EMB_OK) return rc == 1 ? EMB_ERR_ARG : rc;
       return conv_first_bwd_finish(slab, S, (const float*)stats + 4 * Cout, wpack, bias, stats, dW, dbias, dgamma, dbeta, training, B, L, Cin, Cout, k, s);
     }
-    static const bool inline_fin = [] { const char* e = getenv("EMB_BN_INLINE"); return !(e && e[0] == '0'); }();
+    constexpr bool inline_fin = true;
     BnFinBwd fin{};
     bool inl = false;
     if (bn_phase != 2) {
@@ -916,7 +910,7 @@ static int convblock_bwd(const void* dout, int dout_ncl, const uint8_t* argmax, 
       sm = (sm + 15) & ~(size_t)15;
       // bf16, local statistics: the gather pass runs as at most 512 workgroups (one partial row each) and the elementwise
       // pass below finalises dgamma / dbeta / the two means itself from those rows (bn_inline.h): no finalize launch
-      static const bool inline_fin = [] { const char* e = getenv("EMB_BN_INLINE"); return !(e && e[0] == '0'); }();
+      constexpr bool inline_fin = true;
       const bool inl = sizeof(T) == 2 && inline_fin && bn_phase == 0 && Cout <= kBnInlineMaxC && Cout % 8 == 0;
       const int nitems = w.nblk_bwd, nwg = inl && nitems > 512 ? 512 : nitems;
       Rider rd;

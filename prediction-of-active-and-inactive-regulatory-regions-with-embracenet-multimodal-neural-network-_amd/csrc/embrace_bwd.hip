@@ -237,7 +237,7 @@ extern "C" int emb_embrace_bwd_masked(const void* dD0, const void* dD1, const vo
   EMB_CHECK_ARG(dD0 && dD1 && X0 && X1 && W0 && W1 && dW0 && db0 && dW1 && db1, "emb_embrace_bwd_masked: null pointer");
   EMB_CHECK_ARG(emb_embrace_bwd_masked_supported(B, d0, d1, c, dtype),
                 "emb_embrace_bwd_masked: unsupported shape / dtype (see emb_embrace_bwd_masked_supported)");
-  static const int force_S = [] { const char* e = getenv("EMB_BWD_S"); return e ? atoi(e) : 0; }();
+  constexpr int force_S = 0;
   const int rc = dtype == EMB_BF16
                      ? emb::bwd_split_dispatch(nullptr, nullptr, dD0, dD1, X0, X1, W0, W1, dX0, dX1, dW0, db0, dW1, db1, workspace,
                                                workspace_bytes, B, d0, d1, c, force_S, (hipStream_t)stream)
@@ -257,10 +257,9 @@ extern "C" int emb_embrace_bwd(const void* dE, const uint8_t* code, const void* 
   EMB_CHECK_ARG(dE && code && X0 && X1 && W0 && W1 && dW0 && db0 && dW1 && db1, "emb_embrace_bwd: null pointer");
   EMB_CHECK_ARG(B > 0 && d0 > 0 && d1 > 0 && c > 0, "emb_embrace_bwd: bad dims B=%d d0=%d d1=%d c=%d", B, d0, d1, c);
   hipStream_t s = (hipStream_t)stream;
-  if (dtype == EMB_BF16) {   // K split over waves, LDS-DMA rings (embrace_bwd_split.h); EMB_BWD_IMPL=tiled keeps the round-1 kernel
-    static const bool use_split = [] { const char* e = getenv("EMB_BWD_IMPL"); return !(e && strcmp(e, "tiled") == 0); }();
-    static const int force_S = [] { const char* e = getenv("EMB_BWD_S"); return e ? atoi(e) : 0; }();
-    if (use_split) {
+  if (dtype == EMB_BF16) {   // K split over waves, LDS-DMA rings (embrace_bwd_split.h); shapes it refuses take the tiled kernel below
+    constexpr int force_S = 0;
+    {
       const int rc = emb::bwd_split_dispatch(dE, code, nullptr, nullptr, X0, X1, W0, W1, dX0, dX1, dW0, db0, dW1, db1, workspace, workspace_bytes, B, d0, d1, c, force_S, s);
       if (rc != 1) return rc;
     }

@@ -116,7 +116,7 @@ template <typename T> static int fwd_dispatch(const void* X0, const void* X1, co
                                               uint64_t step_val, const uint64_t* step_dev, int64_t row0, void* E,
                                               uint8_t* code, int B, int d0, int d1, int c, hipStream_t s) {
   // EMB_FWD_IMPL=tiled keeps the round-1 kernels (A/B runs); default: K split over waves with LDS-DMA rings
-  static const bool use_split = [] { const char* e = getenv("EMB_FWD_IMPL"); return !(e && strcmp(e, "tiled") == 0); }();
+  constexpr bool use_split = true;
   if (use_split) {
     const int rc = fwd_split_dispatch<T>(X0, X1, W0, b0, W1, b1, sel, u, seed, step_val, step_dev, row0, E, code, B, d0, d1, c, s);
     if (rc != 1) return rc;

@@ -15,7 +15,6 @@ RNG
   element index); no host round trip, no device->host sync, graph-capturable, invariant to how the batch
   is sharded across GPUs.
 """
-import os
 
 import torch
 import torch.nn as nn
@@ -25,7 +24,6 @@ from ._lib import STATUS_INVALID_DISTRIBUTION
 from .prenets import CNN_pre, FFNN_pre
 
 
-_SIDE_STREAMS = {}
 
 
 class _RngMixin:
@@ -309,48 +307,25 @@ class EmbraceNetMultimodal(nn.Module, _RngMixin):
         if getattr(self, "_sel_key", None) != key:      # device copy made once, not per step (no H2D in a graph)
             self._sel_dev, self._sel_key = sp.detach().to(device=dev, dtype=torch.float32).view(1, 2), key
         p = self._sel_dev
-        prep = None
-        if x_FFNN.is_cuda and (getattr(self, "overlap_prenets", False) or os.environ.get("EMB_OVERLAP_PRENETS")):
-            # OPT-IN (model.overlap_prenets = True): the two pre-networks are independent, so the epigenomic MLP and the
-            # selection cdf can run on a side stream next to the sequence CNN (autograd replays each node on its forward
-            # stream, so the backward chains overlap as well; fork/join by events = graph edges under capture).  It paid
-            # while those kernels were slow; with the fused MLP kernels the four fork/join edges cost more than the
-            # ~28 us they hide (measured 0.288 vs 0.280 ms/step in favour of ONE stream), hence off by default
-            cur = torch.cuda.current_stream(dev)
-            side = self._side_stream(dev)
-            side.wait_stream(cur)
-            with torch.cuda.stream(side):
-                h0 = self.FFNN(x_FFNN, rng=rng)
-                prep = self.embracenet._prepare(B, dev, availabilities, p, device_dropout)
+        # The two pre-networks are independent chains.  The epigenomic MLP is tiny and latency-bound, so its launches RIDE on
+        # kernels of the sequence CNN (csrc/rider.h): the forward is parked here and carried by the CNN's first kernel; its
+        # autograd node is attached after the CNN's, so its backward runs first and is carried by the CNN's BatchNorm-backward
+        # pass.  (ride_prenets = False, or a stack the fused kernels do not take: plain launches.  A side stream for the MLP
+        # was measured slower than one stream: the fork / join edges of the captured graph cost more than they hide.)
+        handle = None
+        if rng is not None and getattr(self, "ride_prenets", True) and T == torch.bfloat16:
+            handle = self.FFNN.prelaunch(x_FFNN, rng=rng)
+        if handle is not None:
             h1 = self.CNN(x_CNN, rng=rng)
-            cur.wait_stream(side)
-            h0.record_stream(cur)
-            prep[0].record_stream(cur)
+            h0 = self.FFNN.attach(handle)
         else:
-            # The two pre-networks are independent chains.  The epigenomic MLP is tiny and latency-bound, so its launches
-            # RIDE on kernels of the sequence CNN (csrc/rider.h): the forward is parked here and carried by the CNN's first
-            # kernel; its autograd node is attached after the CNN's, so its backward runs first and is carried by the CNN's
-            # BatchNorm-backward pass.  (ride_prenets = False, or a stack the fused kernels do not take: plain launches.)
-            handle = None
-            if rng is not None and getattr(self, "ride_prenets", True) and T == torch.bfloat16:
-                handle = self.FFNN.prelaunch(x_FFNN, rng=rng)
-            if handle is not None:
-                h1 = self.CNN(x_CNN, rng=rng)
-                h0 = self.FFNN.attach(handle)
-            else:
-                h0, h1 = self.FFNN(x_FFNN, rng=rng), self.CNN(x_CNN, rng=rng)
+            h0, h1 = self.FFNN(x_FFNN, rng=rng), self.CNN(x_CNN, rng=rng)
         E = self.embracenet([h0, h1], availabilities=availabilities, selection_probabilities=p,
-                            _device_dropout=device_dropout, _advance=False, _prep=prep)
+                            _device_dropout=device_dropout, _advance=False)
         out = self._post_forward(E, rng, T)
         if not getattr(self, "defer_step_tick", False):     # a trainer may fold the tick into its loss kernel (step_counter)
             self.embracenet._advance_step()
         return out
-
-    def _side_stream(self, device):
-        st = _SIDE_STREAMS.get(device)          # per process and device, not an attribute: modules stay picklable
-        if st is None:
-            st = _SIDE_STREAMS[device] = torch.cuda.Stream(device=device)
-        return st
 
     def step_counter(self, device):
         """int64 device scalar added to the RNG step of every kernel of a forward.  It must advance by one after each
