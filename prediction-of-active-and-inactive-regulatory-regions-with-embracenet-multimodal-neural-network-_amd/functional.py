@@ -339,6 +339,8 @@ class _EmbraceBypassFn(torch.autograd.Function):
         dX1 = torch.empty(B, c, dtype=T, device=code.device) if ctx.needs_input_grad[1] else None
         check(_lib.lib().emb_embrace_bypass_bwd(ptr(dE), ptr(code), ptr(dX0), ptr(dX1), B, c, DTYPE_CODE[T], stream()),
               "emb_embrace_bypass_bwd")
+        if _AFTER_EMBRACE_BWD is not None:      # (the data-parallel trainers start the first bucket's all-reduce here)
+            _AFTER_EMBRACE_BWD()
         cast = lambda g, d: None if g is None else (g if g.dtype == d else g.to(d))
         return cast(dX0, ctx.in_dtypes[0]), cast(dX1, ctx.in_dtypes[1]), None, None, None, None
 
@@ -405,6 +407,8 @@ class _EmbraceSelectFn(torch.autograd.Function):
         P = (_ct.c_void_p * M)(*[ptr(d) for d in dD])
         check(_lib.lib().emb_embrace_select_bwd(ptr(dE), ptr(code), P, M, B, c, DTYPE_CODE[T], stream()),
               "emb_embrace_select_bwd")
+        if _AFTER_EMBRACE_BWD is not None:
+            _AFTER_EMBRACE_BWD()
         cast = lambda g, d: None if g is None else (g if g.dtype == d else g.to(d))
         return (None, None, None, None) + tuple(cast(g, d) for g, d in zip(dD, ctx.in_dtypes))
 

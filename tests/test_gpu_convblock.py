@@ -306,7 +306,8 @@ def test_first_block_linear_backward_equals_the_recomputing_backward(ea, B, L, s
     of the input and the weights) against the two recomputing passes it replaces, on a REAL-valued input (the lag statistics must
     not rely on one-hot rows) and against autograd in fp64.  Both GPU paths see the same bf16 inputs and round the dense gradient
     tile to bf16 once, in different places: they agree with each other far more closely (measured 2e-3 .. 2e-2 of the largest
-    gradient) than either agrees with fp64 arithmetic on bf16 activations."""
+    gradient; bar 2.5e-2) than either agrees with fp64 arithmetic on bf16 activations -- an error of a few percent in the
+    lag-statistics path would show up as a disagreement of the two paths."""
     L_ = ea._lib.lib()
     x = torch.from_numpy(dg.uniform(f"lin/{B}/{L}/x", (B, 4, L), -1.0, 1.0)).to(torch.bfloat16).double()
     ref_blocks = [Blk(f"lin/{B}/{i}", ci, co, k, torch.float64) for i, (ci, co, k) in enumerate(spec)]
@@ -340,5 +341,11 @@ def test_first_block_linear_backward_equals_the_recomputing_backward(ea, B, L, s
             continue
         s = max(1e-3, r.abs().max().item())
         e_lin, e_rec = (a - r).abs().max().item() / s, (b - r).abs().max().item() / s
-        assert e_lin < TOL["bf16"] * 20 and e_rec < TOL["bf16"] * 20, (nm, e_lin, e_rec)
-        assert (a - b).abs().max().item() / s < 5e-2, (nm, "paths disagree", (a - b).abs().max().item() / s)
+        # measured on MI355X (largest error relative to the largest gradient): the two paths agree to 1.7e-3 .. 1.6e-2; against fp64
+        # arithmetic both carry the SAME error of the bf16 activations / dense gradient tile (weights 7e-2 .. 1.7e-1, relative L2
+        # 8e-2 .. 1.2e-1; gamma / beta of a single-block stack 2e-3 .. 4e-3, behind a second block 6e-2 .. 9e-2)
+        assert e_lin < 0.25 and e_rec < 0.25, (nm, e_lin, e_rec)
+        assert ((a - r).norm() / r.norm()).item() < 0.15 and ((b - r).norm() / r.norm()).item() < 0.15, nm
+        if len(spec) == 1 and nm in ("gamma", "beta"):
+            assert e_lin < 1e-2 and e_rec < 1e-2, (nm, e_lin, e_rec)
+        assert (a - b).abs().max().item() / s < 2.5e-2, (nm, "paths disagree", (a - b).abs().max().item() / s)
