@@ -278,11 +278,12 @@ int emb_ncl_to_nlc(const void* x, int src_dtype, void* out, int dst_dtype, int B
                    emb_stream_t stream);
 int emb_conv_pack_weight(const void* W, void* wpack, void* wflip, int Cout, int Cin, int cin_pad, int k, int dtype,
                          emb_stream_t stream);
-/* Keep bf16 packed images current without a pack launch per step: after emb_conv_pack_register(W, wpack, wflip, ...)
+/* Keep packed images current without a pack launch per step: after emb_conv_pack_register(W, wpack, wflip, ...)
  * every emb_*_step_multi call that updates the fp32 parameter at address W also writes the new values into wpack
- * (and wflip when not NULL), in the layouts of emb_conv_pack_weight.  The caller keeps the buffers alive and
+ * (and wflip when not NULL), in the layouts of emb_conv_pack_weight; `dtype` is the images' element type
+ * (EMB_BF16 for bf16 compute on fp32 masters, EMB_F32 for fp32 compute).  The caller keeps the buffers alive and
  * unregisters before freeing W or them.  Host-side table only; no device work. */
-int emb_conv_pack_register(const void* W, void* wpack, void* wflip, int Cout, int Cin, int cin_pad, int k);
+int emb_conv_pack_register(const void* W, void* wpack, void* wflip, int Cout, int Cin, int cin_pad, int k, int dtype);
 int emb_conv_pack_unregister(const void* W);
 int emb_convblock_fwd(const void* x, const void* wpack, const void* bias, const void* gamma, const void* beta,
                       void* running_mean, void* running_var, int training, double momentum, double eps,

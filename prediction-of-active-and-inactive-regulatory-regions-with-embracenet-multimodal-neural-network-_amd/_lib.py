@@ -59,7 +59,7 @@ SIGNATURES = {
     "emb_convblock_fwd": [_vp] * 7 + [_i, _d, _d, _f, _u64, _u64, _vp, _i64, _i, _vp, _vp, _vp, _vp, _i, _vp, _i64, _vp,
                                      _i, _i, _vp, _i, _i, _i, _i, _i, _i, _vp],
     "emb_convblock_bwd": [_vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _f, _i] + [_vp] * 7 + [_i64, _i, _i, _vp, _i, _i, _i, _i, _i, _i, _i, _vp],
-    "emb_conv_pack_register": [_vp, _vp, _vp, _i, _i, _i, _i],
+    "emb_conv_pack_register": [_vp, _vp, _vp, _i, _i, _i, _i, _i],
     "emb_conv_pack_unregister": [_vp],
     "emb_head_ce_supported": [_i, _i, _i],
     "emb_head_ce_workspace_bytes": [_i, _i],

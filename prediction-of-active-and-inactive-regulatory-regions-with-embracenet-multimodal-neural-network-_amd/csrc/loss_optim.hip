@@ -318,6 +318,7 @@ template <typename P> struct MultiArgs {
   __bf16* sh[kMaxTensors];
   __bf16* flip[kMaxTensors];     // conv weights: tap-flipped packed copy (nullable)
   short pk_k[kMaxTensors], pk_cin[kMaxTensors], pk_cinpad[kMaxTensors], pk_cout[kMaxTensors];   // pk_k == 0: plain shadow
+  signed char pk_f32[kMaxTensors];   // the packed images hold float (fp32 compute) instead of bf16
   int n[kMaxTensors];
   int blk_end[kMaxTensors];     // plain-gradient tensors only (a slab-sourced tensor has no blocks of its own)
   SlabSrc slab[kMaxSrc];
@@ -391,8 +392,14 @@ __device__ __forceinline__ void opt_apply(const MultiArgs<P>& a, const OptConst<
       sh[i] = (__bf16)(float)pi;
     } else {   // registered conv weight W[o][ci][j]: keep its packed images current (see emb_conv_pack_register)
       const int cin = a.pk_cin[t], ii = (int)i, o = ii / (cin * kk), rem = ii - o * cin * kk, ci = rem / kk, j = rem - ci * kk;
-      sh[((long)o * kk + j) * a.pk_cinpad[t] + ci] = (__bf16)(float)pi;
-      if (a.flip[t]) a.flip[t][((long)ci * kk + (kk - 1 - j)) * a.pk_cout[t] + o] = (__bf16)(float)pi;
+      const long ip = ((long)o * kk + j) * a.pk_cinpad[t] + ci, ifl = ((long)ci * kk + (kk - 1 - j)) * a.pk_cout[t] + o;
+      if (a.pk_f32[t]) {
+        reinterpret_cast<float*>(sh)[ip] = (float)pi;
+        if (a.flip[t]) reinterpret_cast<float*>(a.flip[t])[ifl] = (float)pi;
+      } else {
+        sh[ip] = (__bf16)(float)pi;
+        if (a.flip[t]) a.flip[t][ifl] = (__bf16)(float)pi;
+      }
     }
   }
 }
@@ -574,7 +581,7 @@ __global__ __launch_bounds__(256) void multi_opt_kernel(const MultiArgs<P> args,
 struct PackDesc {
   void* wpack;
   void* wflip;
-  int Cout, Cin, cin_pad, k;
+  int Cout, Cin, cin_pad, k, f32;
 };
 static std::unordered_map<const void*, PackDesc>& pack_table() {
   static std::unordered_map<const void*, PackDesc> t;
@@ -626,6 +633,7 @@ static int multi_launch(void* const* params, const void* const* grads, void* con
       a.sh[i] = shadows ? (__bf16*)shadows[j] : nullptr;
       a.flip[i] = nullptr;
       a.pk_k[i] = a.pk_cin[i] = a.pk_cinpad[i] = a.pk_cout[i] = 0;
+      a.pk_f32[i] = 0;
       bool plain = true;
       if (have_ff && i < cnt && (i == fft[0] || i == fft[1] || i == fft[2] || i == fft[3])) plain = false;   // updated by the finish workgroups
       if (i < cnt) {
@@ -639,6 +647,7 @@ static int multi_launch(void* const* params, const void* const* grads, void* con
             a.flip[i] = (__bf16*)it->second.wflip;
             a.pk_k[i] = (short)it->second.k; a.pk_cin[i] = (short)it->second.Cin; a.pk_cinpad[i] = (short)it->second.cin_pad;
             a.pk_cout[i] = (short)it->second.Cout;
+            a.pk_f32[i] = (signed char)it->second.f32;
           }
         }
         // a queued slab reduction that would have produced this gradient: its slices are summed in this launch (reduce.h)
@@ -703,10 +712,11 @@ static int multi_launch(void* const* params, const void* const* grads, void* con
 }
 }  // namespace emb
 
-extern "C" int emb_conv_pack_register(const void* W, void* wpack, void* wflip, int Cout, int Cin, int cin_pad, int k) {
+extern "C" int emb_conv_pack_register(const void* W, void* wpack, void* wflip, int Cout, int Cin, int cin_pad, int k, int dtype) {
   EMB_CHECK_ARG(W && wpack && Cout > 0 && Cin > 0 && cin_pad >= Cin && k > 0, "emb_conv_pack_register: bad argument");
+  EMB_CHECK_ARG(dtype == EMB_BF16 || dtype == EMB_F32, "emb_conv_pack_register: the images are bf16 or f32");
   std::lock_guard<std::mutex> lk(emb::pack_mutex());
-  emb::pack_table()[W] = emb::PackDesc{wpack, wflip, Cout, Cin, cin_pad, k};
+  emb::pack_table()[W] = emb::PackDesc{wpack, wflip, Cout, Cin, cin_pad, k, dtype == EMB_F32};
   return EMB_OK;
 }
 

@@ -74,7 +74,7 @@ def shadow_lookup(w):
 
 
 # Packed images of conv weights (tap-major wpack, tap-flipped wflip; csrc/convblock.hip) cached per Parameter object like
-# the shadows above.  For bf16 compute on fp32 masters the pair is registered with the library, whose fused optimizer
+# the shadows above.  For bf16 or fp32 compute on fp32 masters the pair is registered with the library, whose fused optimizer
 # launches then keep it current in place (emb_conv_pack_register): no pack launch per step.  Any other update of the
 # parameter bumps its version counter and triggers a re-pack here.
 _PACKS = {}
@@ -105,7 +105,7 @@ def conv_packed(w, T, cin_pad, need_flip):
         _pack_drop(id(w), ent[1][1])
         ent = None
     key = (w._version, w.data_ptr(), tuple(w.shape), T, cin_pad)
-    registered = T == torch.bfloat16 and w.dtype == torch.float32    # only then does the optimizer launch maintain the images;
+    registered = T in (torch.bfloat16, torch.float32) and w.dtype == torch.float32   # only then does the optimizer launch maintain the images;
     if registered and ent is not None and ent[1] == key and (ent[3] is not None or not need_flip):   # else: re-pack every call
         return ent[2], ent[3]
     if ent is not None:
@@ -121,8 +121,9 @@ def conv_packed(w, T, cin_pad, need_flip):
     wd = wd if wd.is_contiguous() else wd.contiguous()
     check(_lib.lib().emb_conv_pack_weight(ptr(wd), ptr(wpack), ptr(wflip), Cout, Cin, cin_pad, k, DTYPE_CODE[T], stream()),
           "emb_conv_pack_weight")
-    if T == torch.bfloat16 and w.dtype == torch.float32 and wd.data_ptr() == w.data_ptr():
-        check(_lib.lib().emb_conv_pack_register(w.data_ptr(), ptr(wpack), ptr(wflip), Cout, Cin, cin_pad, k), "emb_conv_pack_register")
+    if registered and wd.data_ptr() == w.data_ptr():
+        check(_lib.lib().emb_conv_pack_register(w.data_ptr(), ptr(wpack), ptr(wflip), Cout, Cin, cin_pad, k, DTYPE_CODE[T]),
+              "emb_conv_pack_register")
         _PACK_REGISTERED[id(w)] = w.data_ptr()
         if id(w) not in _PACK_FINALIZERS:           # the table entry must not outlive the parameter's storage
             _PACK_FINALIZERS.add(id(w))

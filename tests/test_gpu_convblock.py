@@ -150,8 +150,9 @@ def test_full_model_hip_prenets_match_stock_operators(ea):
         assert (a - b).abs().max().item() < 1e-9 * max(1.0, b.abs().max().item())
 
 
-def test_fused_optimizer_keeps_packed_conv_weights_current(ea):
-    """bf16 compute on fp32 masters: the packed images are written by the optimizer launch (emb_conv_pack_register),
+@pytest.mark.parametrize("T", [torch.bfloat16, torch.float32], ids=["bf16", "f32"])
+def test_fused_optimizer_keeps_packed_conv_weights_current(ea, T):
+    """bf16 or fp32 compute on fp32 masters: the packed images are written by the optimizer launch (emb_conv_pack_register),
     no pack kernel per step -- after a step they must equal a fresh pack of the updated parameters."""
     from embracenet_amd import optim
     F = ea.functional
@@ -166,23 +167,26 @@ def test_fused_optimizer_keeps_packed_conv_weights_current(ea):
     x = torch.from_numpy(dg.onehot_sequence("cb/opt/x", 8)).to(DEV)
     for _ in range(3):
         opt.zero_grad()
-        y = F.conv_stack(x, layers, True, rng=F.RngState(seed=1), compute_dtype=torch.bfloat16)
+        y = F.conv_stack(x, layers, True, rng=F.RngState(seed=1), compute_dtype=T)
         y.float().square().mean().backward()
         opt.step()
     torch.cuda.synchronize()
-    cin_pad = 8
+    cin_pad = 8 if T == torch.bfloat16 else 4
+    bits = torch.int16 if T == torch.bfloat16 else torch.int32
     for i, b in enumerate(blocks):
         w = b.conv.weight
         Cout, Cin, k = w.shape
-        wpack, wflip = F.conv_packed(w, torch.bfloat16, cin_pad, need_flip=i > 0)      # cache hit: optimizer-maintained buffers
+        cached = F._PACKS[id(w)]
+        wpack, wflip = F.conv_packed(w, T, cin_pad, need_flip=i > 0)      # cache hit: optimizer-maintained buffers
+        assert wpack.data_ptr() == cached[2].data_ptr() and F._PACKS[id(w)] is cached, f"block {i}: re-packed, not maintained"
         ref_pack = torch.empty_like(wpack)
         ref_flip = torch.empty_like(wflip) if wflip is not None else None
         ea._lib.check(L.emb_conv_pack_weight(ptr(w.detach()), ptr(ref_pack), ptr(ref_flip), Cout, Cin, cin_pad, k,
-                                             ea._lib.DTYPE_CODE[torch.bfloat16], st()), "pack")
+                                             ea._lib.DTYPE_CODE[T], st()), "pack")
         torch.cuda.synchronize()
-        assert torch.equal(wpack.view(torch.int16), ref_pack.view(torch.int16)), f"block {i}: wpack stale"
+        assert torch.equal(wpack.view(bits), ref_pack.view(bits)), f"block {i}: wpack stale"
         if wflip is not None:
-            assert torch.equal(wflip.view(torch.int16), ref_flip.view(torch.int16)), f"block {i}: wflip stale"
+            assert torch.equal(wflip.view(bits), ref_flip.view(bits)), f"block {i}: wflip stale"
         cin_pad = Cout
 
 
