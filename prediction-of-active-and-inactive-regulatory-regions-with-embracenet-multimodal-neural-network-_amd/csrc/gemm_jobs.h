@@ -35,10 +35,10 @@ namespace emb {
 constexpr int kGjThreads = 512;
 constexpr int kGjKC = 32;                         // reduction indices per stage
 constexpr int kGjStage = 32 * 1024;               // m-side image (16 KB) + n-side image (16 KB)
-constexpr int kGjSlots = 5;
-constexpr int kGjLds = kGjSlots * kGjStage;       // 160 KB
 constexpr int kGjDma = 4;                         // LDS-DMA instructions per wave and stage
-constexpr int kGjAhead = kGjSlots - 1;            // stages in flight ahead of the one being multiplied
+// ring depth, a template parameter of the kernel: 5 slots (160 KB: one workgroup per CU, four stages requested ahead) or 2 slots
+// (64 KB: TWO workgroups per CU, one stage ahead)
+template <int SLOTS> constexpr int kGjLds = SLOTS * kGjStage;
 
 struct GJob {
   const char* A;        // m-side operand (pre-masked gradient)
@@ -263,26 +263,27 @@ __device__ __forceinline__ void gj_feed_tile(GFeed& f, const GTile& t, int lane,
 // takes 64 B per clock, 32 KB per stage = 512 cycles per CU), which hides under the other waves' MFMAs only when the eight
 // waves do not all issue at once right after the barrier.
 __device__ __forceinline__ bool gj_more(const GFeed& f) { return f.stage < f.nstages; }
-template <int I> __device__ __forceinline__ void gj_part(GFeed& f, uint32_t lds0) {
+template <int I, int SLOTS> __device__ __forceinline__ void gj_part(GFeed& f, uint32_t lds0) {
+  constexpr int IA = I < 2 ? I : 0, IB = I >= 2 ? I - 2 : 0;   // (in-range indices for the branches I does not take)
   const uint32_t buf = lds0 + (uint32_t)(f.slot * kGjStage) + f.dst[I];
   if (f.kind == 2 && I < 2) {                      // activation rows shifted by the stage's tap
     const int sh = f.tap - f.pad;
-    const bool ok = (unsigned)(f.lpos[I] + sh) < (unsigned)f.L;
-    gj_dma(f.ra, buf, ok ? f.cbase[I] + (uint32_t)(sh * f.cin4 + f.cb * 128) : kDmaInvalid);
+    const bool ok = (unsigned)(f.lpos[IA] + sh) < (unsigned)f.L;
+    gj_dma(f.ra, buf, ok ? f.cbase[IA] + (uint32_t)(sh * f.cin4 + f.cb * 128) : kDmaInvalid);
     if (I == 1) { if (++f.cb == f.cpt) { f.cb = 0; ++f.tap; } }
     return;
   }
   if (f.kind == 3 && I >= 2) {                     // activation rows shifted by the quarter's tap
-    const int sh = f.qtap[I - 2] - f.pad;
-    const bool ok = f.cbase[I - 2] != kDmaInvalid && (unsigned)(f.lpos[0] + sh) < (unsigned)f.L;
+    const int sh = f.qtap[IB] - f.pad;
+    const bool ok = f.cbase[IB] != kDmaInvalid && (unsigned)(f.lpos[0] + sh) < (unsigned)f.L;
     const int r = f.krow0 + f.stage * kGjKC + sh;
-    gj_dma(f.rb, buf, ok ? (uint32_t)r * (uint32_t)f.cin4 + f.cbase[I - 2] : kDmaInvalid);
+    gj_dma(f.rb, buf, ok ? (uint32_t)r * (uint32_t)f.cin4 + f.cbase[IB] : kDmaInvalid);
     if (I == 3) {
       int l = f.lpos[0] + kGjKC;                   // position of the next stage's row inside its sequence (L >= 16)
       if (l >= f.L) l -= f.L;
       if (l >= f.L) l -= f.L;
       f.lpos[0] = l;
-      f.slot = f.slot + 1 == kGjSlots ? 0 : f.slot + 1;
+      f.slot = f.slot + 1 == SLOTS ? 0 : f.slot + 1;
       ++f.stage;
     }
     return;
@@ -297,13 +298,13 @@ template <int I> __device__ __forceinline__ void gj_part(GFeed& f, uint32_t lds0
     f.off[I] += f.step_b;
   }
   if (I == 3) {
-    f.slot = f.slot + 1 == kGjSlots ? 0 : f.slot + 1;
+    f.slot = f.slot + 1 == SLOTS ? 0 : f.slot + 1;
     ++f.stage;
   }
 }
-__device__ __forceinline__ bool gj_request(GFeed& f, uint32_t lds0) {
+template <int SLOTS> __device__ __forceinline__ bool gj_request(GFeed& f, uint32_t lds0) {
   if (!gj_more(f)) return false;
-  gj_part<0>(f, lds0); gj_part<1>(f, lds0); gj_part<2>(f, lds0); gj_part<3>(f, lds0);
+  gj_part<0, SLOTS>(f, lds0); gj_part<1, SLOTS>(f, lds0); gj_part<2, SLOTS>(f, lds0); gj_part<3, SLOTS>(f, lds0);
   return true;
 }
 #endif
@@ -322,7 +323,8 @@ struct GHalf {                                    // fragments of one half of a 
   float b[2][4];                                  // m side: [row tile][step j]
 };
 
-__global__ __launch_bounds__(kGjThreads, 2) void gemm_jobs_kernel(const GArgs args) {
+template <int SLOTS>
+__global__ __launch_bounds__(kGjThreads, SLOTS == 2 ? 4 : 2) void gemm_jobs_kernel(const GArgs args) {
 #if defined(__HIP_DEVICE_COMPILE__)
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const gj_args_ptr ka = (gj_args_ptr)__builtin_amdgcn_kernarg_segment_ptr();
@@ -339,7 +341,7 @@ __global__ __launch_bounds__(kGjThreads, 2) void gemm_jobs_kernel(const GArgs ar
   gj_feed_tile(feed, t, lane, wave);
   int requested = 0;                                 // stages requested so far
 #pragma unroll 1
-  for (int i = 0; i < kGjAhead; ++i) requested += gj_request(feed, lds0) ? 1 : 0;
+  for (int i = 0; i < SLOTS - 1; ++i) requested += gj_request<SLOTS>(feed, lds0) ? 1 : 0;
   requested = __builtin_amdgcn_readfirstlane(requested);
   EMB_STAMP(3);
 
@@ -415,12 +417,18 @@ __global__ __launch_bounds__(kGjThreads, 2) void gemm_jobs_kernel(const GArgs ar
 
   int slot = 0;
   GHalf f0, f1;
-  // stage 0: visible after this barrier; its first half's fragments are read ahead of the loop
-  gj_wait(requested - 1);
-  __builtin_amdgcn_s_barrier();
-  asm volatile("" ::: "memory");
+  if constexpr (SLOTS > 2) {
+    // stage 0: visible after this barrier; its first half's fragments are read ahead of the loop
+    gj_wait(requested - 1);
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+  }
   EMB_STAMP(4);
+  if constexpr (SLOTS > 2) load(lds0, t.kind, 0, f0);
+#ifdef GJ_DIAG_NO_LOAD
   load(lds0, t.kind, 0, f0);
+  load(lds0, t.kind, 1, f1);
+#endif
   {
     f32x4 acc[4][2];                                 // [n tile][m tile]
     float sb[2] = {0.0f, 0.0f};                      // wgrad, first n tile: this lane's share of the bias gradient
@@ -432,24 +440,9 @@ __global__ __launch_bounds__(kGjThreads, 2) void gemm_jobs_kernel(const GArgs ar
         for (int q = 0; q < 4; ++q) acc[ni][mi][q] = 0.0f;
     const bool with_bias = (t.kind == 1 || t.kind == 3) && t.n0 == 0 && wc == 0;
     EMB_STAMP_KIND(t.kind);
-    // waves w and w + 4 share a SIMD: the second half issues each DMA instruction one MFMA group EARLIER than its partner, so
-    // that one of the two is multiplying while the other sits in the ~150 cycles an LDS-DMA instruction takes to issue
-    const bool early = wave >= 4;
-#pragma unroll 1
-    for (int s = 0; s < t.nstages; ++s) {
-      const bool more = s + 1 < t.nstages;           // another stage follows this one
-      // make the next stage visible (its fragments are read while this stage's second half is multiplied); every wave
-      // has then also finished the stage multiplied before this one: its slot takes the next request
-      if (more) gj_wait(requested - s - 2);
-      __builtin_amdgcn_s_barrier();                  // raw barrier: a __syncthreads() would drain the younger stages
-      asm volatile("" ::: "memory");
-      const bool feeding = gj_more(feed);
-      requested += feeding ? 1 : 0;
-      if (feeding && early) gj_part<0>(feed, lds0);
-      const uint32_t buf = lds0 + (uint32_t)(slot * kGjStage);
-      slot = slot + 1 == kGjSlots ? 0 : slot + 1;
-      const uint32_t nbuf = lds0 + (uint32_t)(slot * kGjStage);
-      load(buf, t.kind, 1, f1);
+#ifdef GJ_DIAG_NO_MMA
+#define GJ_MMA(F, J0) asm volatile("" : : "v"(F.a[0][J0]), "v"(F.a[1][J0]), "v"(F.a[2][J0 + 1]), "v"(F.a[3][J0 + 1]), "v"(F.b[0][J0]), "v"(F.b[1][J0 + 1]))
+#else
 #define GJ_MMA(F, J0)                                                                                                        \
       __builtin_amdgcn_sched_barrier(0);                                                                                     \
       _Pragma("unroll") for (int j = J0; j < J0 + 2; ++j) {                                                                  \
@@ -460,21 +453,85 @@ __global__ __launch_bounds__(kGjThreads, 2) void gemm_jobs_kernel(const GArgs ar
         }                                                                                                                    \
       }                                                                                                                      \
       __builtin_amdgcn_sched_barrier(0)
+#endif
+    if constexpr (SLOTS == 2) {
+      // two workgroups per CU (four waves per SIMD): the other workgroup's MFMAs fill this one's barrier, LDS-latency and
+      // DMA-issue phases, so the schedule is the plain double buffer: the stage is visible after the barrier, which also frees
+      // the other slot (every wave has multiplied the previous stage) for the next request; its first two DMA instructions are
+      // issued under the first half's fragment reads, the other two (and the second half's reads) after the first MFMA group
+      // (three quarters of a stage left to land)
+#pragma unroll 1
+      for (int s = 0; s < t.nstages; ++s) {
+        EMB_WAIT_VMCNT(0);
+#ifndef GJ_DIAG_NO_BARRIER
+        __builtin_amdgcn_s_barrier();
+#endif
+        asm volatile("" ::: "memory");
+#ifdef GJ_DIAG_NO_DMA
+        const bool feeding = false;
+#else
+        const bool feeding = gj_more(feed);
+#endif
+        const uint32_t buf = lds0 + (uint32_t)(slot * kGjStage);
+        slot ^= 1;
+#ifndef GJ_DIAG_NO_LOAD
+        load(buf, t.kind, 0, f0);
+#endif
+        if (feeding) { gj_part<0, SLOTS>(feed, lds0); gj_part<1, SLOTS>(feed, lds0); }
+        GJ_MMA(f0, 0);
+#ifndef GJ_DIAG_NO_LOAD
+        load(buf, t.kind, 1, f1);
+#endif
+        if (feeding) { gj_part<2, SLOTS>(feed, lds0); gj_part<3, SLOTS>(feed, lds0); }
+        GJ_MMA(f0, 2);
+        GJ_MMA(f1, 0);
+        GJ_MMA(f1, 2);
+      }
+    } else {
+    // waves w and w + 4 share a SIMD: the second half issues each DMA instruction one MFMA group EARLIER than its partner, so
+    // that one of the two is multiplying while the other sits in the ~150 cycles an LDS-DMA instruction takes to issue
+    const bool early = wave >= 4;
+#pragma unroll 1
+    for (int s = 0; s < t.nstages; ++s) {
+      const bool more = s + 1 < t.nstages;           // another stage follows this one
+      // make the next stage visible (its fragments are read while this stage's second half is multiplied); every wave
+      // has then also finished the stage multiplied before this one: its slot takes the next request
+      if (more) gj_wait(requested - s - 2);
+#ifndef GJ_DIAG_NO_BARRIER
+      __builtin_amdgcn_s_barrier();                  // raw barrier: a __syncthreads() would drain the younger stages
+#endif
+      asm volatile("" ::: "memory");
+#ifdef GJ_DIAG_NO_DMA
+      const bool feeding = false;
+#else
+      const bool feeding = gj_more(feed);
+#endif
+      requested += feeding ? 1 : 0;
+      if (feeding && early) gj_part<0, SLOTS>(feed, lds0);
+      const uint32_t buf = lds0 + (uint32_t)(slot * kGjStage);
+      slot = slot + 1 == SLOTS ? 0 : slot + 1;
+      const uint32_t nbuf = lds0 + (uint32_t)(slot * kGjStage);
+#ifndef GJ_DIAG_NO_LOAD
+      load(buf, t.kind, 1, f1);
+#endif
       GJ_MMA(f0, 0);
-      if (feeding) { if (early) gj_part<1>(feed, lds0); else gj_part<0>(feed, lds0); }
+      if (feeding) { if (early) gj_part<1, SLOTS>(feed, lds0); else gj_part<0, SLOTS>(feed, lds0); }
       GJ_MMA(f0, 2);
-      if (feeding) { if (early) gj_part<2>(feed, lds0); else gj_part<1>(feed, lds0); }
+      if (feeding) { if (early) gj_part<2, SLOTS>(feed, lds0); else gj_part<1, SLOTS>(feed, lds0); }
+#ifndef GJ_DIAG_NO_LOAD
       if (more) load(nbuf, t.kind, 0, f0);
+#endif
       GJ_MMA(f1, 0);
-      if (feeding) { if (early) gj_part<3>(feed, lds0); else gj_part<2>(feed, lds0); }
+      if (feeding) { if (early) gj_part<3, SLOTS>(feed, lds0); else gj_part<2, SLOTS>(feed, lds0); }
       GJ_MMA(f1, 2);
-      if (feeding && !early) gj_part<3>(feed, lds0);
-#undef GJ_MMA
+      if (feeding && !early) gj_part<3, SLOTS>(feed, lds0);
       // the compiler's wait-count model gives up on LDS reads that are pending across the loop edge (it would wait for
       // everything, the reads just issued included, before the next iteration's first MFMA): pin the arrival of f0 here
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
       asm volatile("" : : "v"(f0.a[0][0]), "v"(f0.a[1][1]), "v"(f0.a[2][2]), "v"(f0.a[3][3]), "v"(f0.b[0][0]), "v"(f0.b[1][3]));
     }
+    }
+#undef GJ_MMA
     EMB_STAMP(5);
     // the tile leaves from registers.  Accumulator (ni, mi) of lane (r, g): row 32 wr + 16 mi + r, columns 64 wc + 16 ni + 4 g .. + 3.
     {
@@ -557,6 +614,35 @@ __global__ __launch_bounds__(kGjThreads, 2) void gemm_jobs_kernel(const GArgs ar
 #endif
 }
 
+// One tile per workgroup.  With enough tiles for two workgroups on every CU the two-slot kernel runs (64 KB of LDS each): four
+// waves per SIMD keep the fp32 matrix pipe fed through each other's barriers, fragment reads and DMA issue (two waves of ONE
+// workgroup leave it idle ~30 % of the loop, tools/kbench variants), and a workgroup's set-up and stores run under its
+// neighbour's main loop.  Fewer tiles: one workgroup per CU, five slots, four stages requested ahead.
+static int gj_cus() {
+  static const int cus = [] {
+    int dev = 0, v = 256;
+    if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev);
+    return v > 0 ? v : 256;
+  }();
+  return cus;
+}
+static void gj_launch(const GArgs& ga, int n, hipStream_t s) {
+  const int cus = gj_cus();
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_jobs_kernel<5>), hipFuncAttributeMaxDynamicSharedMemorySize, kGjLds<5>);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_jobs_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, kGjLds<2>);
+    attr_set = true;
+  }
+#ifdef GJ_DIAG_FORCE_SLOTS
+  const bool two = GJ_DIAG_FORCE_SLOTS == 2;
+#else
+  const bool two = n > cus + cus / 4;
+#endif
+  if (two) gemm_jobs_kernel<2><<<n, kGjThreads, kGjLds<2>, s>>>(ga);
+  else gemm_jobs_kernel<5><<<n, kGjThreads, kGjLds<5>, s>>>(ga);
+}
+
 // returns 1 when the shapes do not qualify (the caller keeps its other kernels)
 static int gemm_jobs_bwd_impl(const void* dD0, const void* dD1, const void* X0, const void* X1, const void* W0, const void* W1,
                                   void* dX0, void* dX1, void* dW0, void* db0, void* dW1, void* db1, void* ws, int64_t ws_bytes, int B,
@@ -573,6 +659,7 @@ static int gemm_jobs_bwd_impl(const void* dD0, const void* dD1, const void* X0, 
   struct SlabInfo { float* slab; int pitch; int S; } slabs[2] = {{nullptr, 0, 1}, {nullptr, 0, 1}};
   auto wgrad = [&](const void* dD, const void* X, void* dW, void* db, int d, int m) {
     GJob j{};
+    if (dD == nullptr) { j.first = n; return j; }    // no such modality (a single Linear layer's backward, linear.hip)
     j.A = (const char*)dD; j.Bm = (const char*)X; j.C = (char*)dW; j.bias = (float*)db;
     j.M = c; j.N = d; j.K = B; j.lda = c; j.ldb = d; j.ldc = d;
     j.tiles_m = cdiv(c, 128); j.tiles_n = cdiv(d, 128); j.tiles = j.tiles_m * j.tiles_n;
@@ -606,6 +693,7 @@ static int gemm_jobs_bwd_impl(const void* dD0, const void* dD1, const void* X0, 
   };
   auto dgrad = [&](const void* dD, const void* W, void* dX, int d) {
     GJob j{};
+    if (dD == nullptr) { j.first = n; return j; }
     j.A = (const char*)dD; j.Bm = (const char*)W; j.C = (char*)dX;
     j.M = B; j.N = d; j.K = c; j.lda = c; j.ldb = d; j.ldc = d;
     j.tiles_m = cdiv(B, 128); j.tiles_n = cdiv(d, 128); j.tiles = j.tiles_m * j.tiles_n;
@@ -632,11 +720,6 @@ static int gemm_jobs_bwd_impl(const void* dD0, const void* dD1, const void* X0, 
       dg1 = dgrad(dD1, W1, dX1, d1); dg0 = dgrad(dD0, W0, dX0, d0);
     }
   }
-  static bool attr_set = false;
-  if (!attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_jobs_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, kGjLds);
-    attr_set = true;
-  }
   GArgs ga{};
   {   // in list order (the range starts `first` ascend)
     GJob all[4] = {wg1, dg1, wg0, dg0};
@@ -646,7 +729,7 @@ static int gemm_jobs_bwd_impl(const void* dD0, const void* dD1, const void* X0, 
     for (int a = 0; a < 4; ++a) ga.j[a] = all[a];
   }
   ga.total = n;
-  gemm_jobs_kernel<<<n, kGjThreads, kGjLds, s>>>(ga);
+  gj_launch(ga, n, s);
   EMB_CHECK_LAUNCH();
   for (int m = 1; m >= 0; --m) {
     if (slabs[m].S > 1) {
@@ -662,13 +745,6 @@ static int gemm_jobs_bwd_impl(const void* dD0, const void* dD1, const void* X0, 
 }
 
 // ---- fp32 convolutions of the stored-activation blocks as ring GEMM jobs (csrc/convblock.hip dispatches here) ---------------------
-static void gj_attr() {
-  static bool attr_set = false;
-  if (!attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_jobs_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, kGjLds);
-    attr_set = true;
-  }
-}
 static bool gj_conv_ok(int B, int L, int cin, int N, int KK) {
   const long R = (long)B * L;
   // N >= 128: a 128-wide tile on fewer output channels leaves whole waves idle (measured at 64: slower than conv_direct.hip)
@@ -695,8 +771,7 @@ static int gemm_jobs_conv_impl(bool fwd, const void* x, const void* w, const voi
   ga.j[0] = j;
   for (int a = 1; a < 4; ++a) { ga.j[a] = GJob{}; ga.j[a].first = j.count; }
   ga.total = j.count;
-  gj_attr();
-  gemm_jobs_kernel<<<j.count, kGjThreads, kGjLds, s>>>(ga);
+  gj_launch(ga, j.count, s);
   EMB_CHECK_LAUNCH();
   if (partial_rows != nullptr) *partial_rows = j.tiles_m;
   return EMB_OK;
@@ -725,8 +800,7 @@ static int gemm_jobs_conv_wgrad_impl(const void* dy, const void* x, void* slab, 
   ga.j[0] = j;
   for (int a = 1; a < 4; ++a) { ga.j[a] = GJob{}; ga.j[a].first = j.count; }
   ga.total = j.count;
-  gj_attr();
-  gemm_jobs_kernel<<<j.count, kGjThreads, kGjLds, s>>>(ga);
+  gj_launch(ga, j.count, s);
   EMB_CHECK_LAUNCH();
   return EMB_OK;
 }

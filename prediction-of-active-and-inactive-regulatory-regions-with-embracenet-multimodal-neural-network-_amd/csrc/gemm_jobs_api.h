@@ -5,7 +5,8 @@
 
 namespace emb {
 
-// EmbraceNet backward on pre-masked gradients (emb_embrace_bwd_masked, EMB_F32)
+// EmbraceNet backward on pre-masked gradients (emb_embrace_bwd_masked, EMB_F32).  dD1 == nullptr: one modality only -- the
+// backward of a single Linear layer y = x W^T + b on its pre-masked gradient (linear.hip): c = out features, d0 = in features
 int gemm_jobs_bwd(const void* dD0, const void* dD1, const void* X0, const void* X1, const void* W0, const void* W1, void* dX0, void* dX1,
                   void* dW0, void* db0, void* dW1, void* db1, void* ws, int64_t ws_bytes, int B, int d0, int d1, int c, int force_S,
                   hipStream_t s);

@@ -4,9 +4,23 @@
 // epilogue; backward applies the saved mask while dY is staged and folds the bias gradient into the
 // weight-gradient GEMM (virtual ones row), all in one launch.
 #include "gemm_tile.h"
+#include "gemm_jobs_api.h"
 #include "reduce.h"
 
 namespace emb {
+
+// dZ = dY * [mask bits set] * scale: the gradient behind ReLU / inverted dropout, written once for the fp32 ring GEMM
+__global__ __launch_bounds__(256) void linear_premask_kernel(const float* __restrict__ dY, const uint8_t* __restrict__ mask,
+                                                             float* __restrict__ dZ, long n4, uint8_t need, float scale) {
+  const long i = (long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n4) return;
+  const f32x4 v = reinterpret_cast<const f32x4*>(dY)[i];
+  const uint32_t m = reinterpret_cast<const uint32_t*>(mask)[i];
+  f32x4 o;
+#pragma unroll
+  for (int e = 0; e < 4; ++e) o[e] = (((m >> (8 * e)) & need) == need) ? v[e] * scale : 0.0f;
+  reinterpret_cast<f32x4*>(dZ)[i] = o;
+}
 
 template <typename T> struct LinCfg;
 template <> struct LinCfg<float> {
@@ -104,6 +118,30 @@ static int linear_bwd_dispatch(const void* dY, const uint8_t* mask, const void* 
   using CD = typename LinCfg<T>::D;
   using CW = typename LinCfg<T>::W;
   constexpr int VEC = Elem<T>::VEC;
+  if constexpr (sizeof(T) == 4) {
+    // large fp32 layers (the first post layer of a wide fusion: 1024 -> 256 at B = 1024): the ring GEMM of gemm_jobs.h on the
+    // pre-masked gradient -- a Linear layer's backward is one modality of the docking backward (c = N out, d = K in).
+    // The 64 x 64 x 32 tiles below run such a layer at ~12 TFLOP/s (89 us at cfg4).
+    const int64_t dz_bytes = ((int64_t)B * N * 4 + 255) & ~(int64_t)255;
+    const bool masked = mask != nullptr && (relu || dropout_p > 0.f);
+    if ((long)B * K * N >= (1l << 27) && K % 4 == 0 && N % 4 == 0 && ((long)B * N) % 4 == 0 && ws != nullptr && aligned16(ws) && aligned16(dY) &&
+        (!masked || ((reinterpret_cast<uintptr_t>(mask) & 3u) == 0 && ws_bytes >= dz_bytes))) {
+      const void* dZ = dY;
+      int64_t used = 0;
+      if (masked) {
+        const long n4 = (long)B * N / 4;
+        linear_premask_kernel<<<(unsigned)((n4 + 255) / 256), 256, 0, s>>>((const float*)dY, mask, (float*)ws, n4,
+                                                                           (uint8_t)((relu ? 1 : 0) | (dropout_p > 0.f ? 2 : 0)),
+                                                                           dropout_p > 0.f ? 1.0f / (1.0f - dropout_p) : 1.0f);
+        EMB_CHECK_LAUNCH();
+        dZ = ws;
+        used = dz_bytes;
+      }
+      const int rc = gemm_jobs_bwd(dZ, nullptr, X, nullptr, W, nullptr, dX, nullptr, dW, db, nullptr, nullptr, (char*)ws + used,
+                                   ws_bytes - used, B, K, 0, N, 0, s);
+      if (rc != 1) return rc;      // 1: the shapes do not qualify -- the tile kernel below takes the layer
+    }
+  }
   LinBwdArgs<T> a;
   const bool vn = (N % VEC == 0) && aligned16(dY) && (mask == nullptr || (reinterpret_cast<uintptr_t>(mask) & 7u) == 0);
   const bool vk = (K % VEC == 0) && aligned16(X) && aligned16(W);

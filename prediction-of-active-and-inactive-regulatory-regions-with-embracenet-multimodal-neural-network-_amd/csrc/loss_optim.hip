@@ -360,30 +360,41 @@ __device__ __forceinline__ OptElem<P> opt_load(const MultiArgs<P>& a, int t, lon
   e.v = a.v[t][i];
   return e;
 }
+// the update itself: element (p, m, v) and its gradient (raw, weight-decay-free) -> the new element
 template <typename P, int OPT>
-__device__ __forceinline__ void opt_apply(const MultiArgs<P>& a, const OptConst<P>& k, int t, long i, P graw, const OptElem<P>& e) {
-  P* p = a.p[t];
-  P* m = a.m[t];
-  P* v = a.v[t];
+__device__ __forceinline__ OptElem<P> opt_math(const OptConst<P>& k, P graw, const OptElem<P>& e) {
+  OptElem<P> o;
   P pi = e.p;
   const P gi = graw + k.pwd * pi;
   if (OPT == OPT_ADAM) {
     const P mi = e.m + (gi - e.m) * k.omb1;
     const P vi = e.v * k.pb2 + gi * gi * k.omb2;
     pi -= k.c1 * (mi / (sqrt(vi) / k.bc2s + k.peps));
-    m[i] = mi; v[i] = vi;
+    o.m = mi; o.v = vi;
   } else if (OPT == OPT_RMSPROP) {
     const P si = e.v * k.pa + gi * gi * k.oma;
     pi -= k.plr * (gi / (sqrt(si) + k.peps));
-    v[i] = si;
+    o.m = (P)0; o.v = si;
   } else {
     const P mi = e.m * k.pb1 + gi * k.omb1;
     const P vi = e.v * k.pb2 + gi * gi * k.omb2;
     const P denom = sqrt(vi) / k.bc2s + k.peps;
     pi -= k.c1 * (gi / denom);
     pi -= k.c2 * (mi / denom);
-    m[i] = mi; v[i] = vi;
+    o.m = mi; o.v = vi;
   }
+  o.p = pi;
+  return o;
+}
+template <typename P, int OPT>
+__device__ __forceinline__ void opt_apply(const MultiArgs<P>& a, const OptConst<P>& k, int t, long i, P graw, const OptElem<P>& e) {
+  P* p = a.p[t];
+  P* m = a.m[t];
+  P* v = a.v[t];
+  const OptElem<P> o = opt_math<P, OPT>(k, graw, e);
+  const P pi = o.p;
+  if (OPT != OPT_RMSPROP) m[i] = o.m;
+  v[i] = o.v;
   p[i] = pi;
   __bf16* sh = a.sh[t];
   if (sh) {
@@ -406,6 +417,40 @@ __device__ __forceinline__ void opt_apply(const MultiArgs<P>& a, const OptConst<
 template <typename P, int OPT>
 __device__ __forceinline__ void opt_update(const MultiArgs<P>& a, const OptConst<P>& k, int t, long i, P graw) {
   opt_apply<P, OPT>(a, k, t, i, graw, opt_load<P, OPT>(a, t, i));
+}
+// four consecutive elements i0 .. i0 + 3 of tensor t with whole-vector accesses (their summed gradients g4 are also written to
+// the tensor's .grad); false: not applicable (alignment, or a registered conv weight whose images need the per-element path)
+template <typename P, int OPT>
+__device__ __forceinline__ bool opt_update4(const MultiArgs<P>& a, const OptConst<P>& k, int t, long i0, const P (&g4)[4]) {
+  typedef P P4 __attribute__((ext_vector_type(4)));
+  P* p = a.p[t] + i0;
+  P* m = OPT == OPT_RMSPROP ? p : a.m[t] + i0;
+  P* v = a.v[t] + i0;
+  P* g = a.g[t] + i0;
+  __bf16* sh = a.sh[t];
+  if (((reinterpret_cast<uintptr_t>(p) | reinterpret_cast<uintptr_t>(m) | reinterpret_cast<uintptr_t>(v) | reinterpret_cast<uintptr_t>(g)) &
+       (sizeof(P4) - 1)) != 0 || (sh != nullptr && (a.pk_k[t] != 0 || (reinterpret_cast<uintptr_t>(sh + i0) & 7) != 0)))
+    return false;
+  const P4 pv = *reinterpret_cast<const P4*>(p), vv = *reinterpret_cast<const P4*>(v);
+  P4 mv = {0, 0, 0, 0};
+  if (OPT != OPT_RMSPROP) mv = *reinterpret_cast<const P4*>(m);
+  P4 po, mo, vo, go;
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    const OptElem<P> o = opt_math<P, OPT>(k, g4[e], OptElem<P>{pv[e], mv[e], vv[e]});
+    po[e] = o.p; mo[e] = o.m; vo[e] = o.v; go[e] = g4[e];
+  }
+  *reinterpret_cast<P4*>(g) = go;
+  if (OPT != OPT_RMSPROP) *reinterpret_cast<P4*>(m) = mo;
+  *reinterpret_cast<P4*>(v) = vo;
+  *reinterpret_cast<P4*>(p) = po;
+  if (sh != nullptr) {
+    bf16x4 b;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) b[e] = (__bf16)(float)po[e];
+    *reinterpret_cast<bf16x4*>(sh + i0) = b;
+  }
+  return true;
 }
 
 // slab element q of a job -> (output of the job, element of that output); false: padding
@@ -545,6 +590,37 @@ __global__ __launch_bounds__(256) void multi_opt_kernel(const MultiArgs<P> args,
   const P* in = (const P*)sj.in;
   P acc[4] = {0, 0, 0, 0};
   const long q0 = ((long)jb * qpb + qi) * sj.vec;
+  if (lanes == 1 && sj.vec == 4) {
+    // large slabs (the docking / post-layer weight gradients): every thread sums all slices of ITS four elements (independent
+    // 16-byte loads) and updates them with whole-vector accesses of p, m, v, g -- no exchange, one memory round trip.  (With
+    // several lanes per element the update below touches 4 bytes per thread at a 16-byte stride: a quarter of every sector.)
+    if (q0 >= per) return;
+    typedef P P4 __attribute__((ext_vector_type(4)));
+    P4 s4 = {0, 0, 0, 0};
+#pragma unroll 8
+    for (int s = 0; s < sj.S; ++s) s4 += *reinterpret_cast<const P4*>(in + (long)s * per + q0);
+    const P g4[4] = {s4[0], s4[1], s4[2], s4[3]};
+    int w0 = 0, w3 = 0;
+    long i0 = 0, i3 = 0;
+    const bool ok0 = slab_target(sj, q0, &w0, &i0), ok3 = slab_target(sj, q0 + 3, &w3, &i3);
+    if (ok0 && ok3 && w0 == w3 && i3 == i0 + 3 && sj.tensor[w0] >= 0 && opt_update4<P, OPT>(a, kc, sj.tensor[w0], i0, g4)) return;
+    int tt[4];
+    long ii[4];
+    OptElem<P> el[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {                       // all loads first (see opt_load)
+      int which;
+      tt[e] = slab_target(sj, q0 + e, &which, &ii[e]) ? sj.tensor[which] : -1;
+      if (tt[e] >= 0) el[e] = opt_load<P, OPT>(a, tt[e], ii[e]);
+    }
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      if (tt[e] < 0) continue;
+      a.g[tt[e]][ii[e]] = g4[e];
+      opt_apply<P, OPT>(a, kc, tt[e], ii[e], g4[e], el[e]);
+    }
+    return;
+  }
   if (q0 < per) {
     if (sj.vec == 4) {
       typedef P P4 __attribute__((ext_vector_type(4)));
@@ -664,8 +740,10 @@ static int multi_launch(void* const* params, const void* const* grads, void* con
             for (int q = 0; q < 8; ++q) d.tensor[q] = -1;
             int lanes = 1;
             while (lanes < 16 && lanes < cl.job.S) lanes *= 2;
+            d.vec = (cl.job.per % 4 == 0 && aligned16(cl.job.in) && (sizeof(P) == 4 || (reinterpret_cast<uintptr_t>(cl.job.in) & 31) == 0)) ? 4 : 1;
+            // large row-major slabs: one thread per four elements, whole-vector updates (multi_opt_kernel)
+            if (d.vec == 4 && cl.job.per >= 32768 && (cl.job.kind == RJ_LINEAR || cl.job.kind == RJ_MLP)) lanes = 1;
             d.lanes = lanes;
-            d.vec = (cl.job.per % 4 == 0 && aligned16(cl.job.in)) ? 4 : 1;
           }
           if (k >= 0) {
             a.slab[k].tensor[cl.which] = (signed char)i;

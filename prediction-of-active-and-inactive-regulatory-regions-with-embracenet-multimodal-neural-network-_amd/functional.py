@@ -453,7 +453,9 @@ class _LinearFn(torch.autograd.Function):
         dx = torch.empty(B, K, dtype=T, device=xc.device) if ctx.needs_input_grad[0] else None
         sk = ctx.sinks
         dw, db = _out(sk[0], (N, K), P, xc.device), _out(sk[1], (N,), P, xc.device)
-        ws = _workspace(xc.device, 1 << 22, f"linear{ctx.layer_id}", ctx.ws_owner)
+        # scratch: weight-gradient slabs of the batch slices; large fp32 layers also park the pre-masked gradient there (linear.hip)
+        nbytes = max(1 << 22, B * N * 4 + 4 * N * (K + 4) * 4 + 4096) if T == torch.float32 else 1 << 22
+        ws = _workspace(xc.device, nbytes, f"linear{ctx.layer_id}", ctx.ws_owner)
         check(_lib.lib().emb_linear_bwd(ptr(dy), ptr(mask), ptr(xc), ptr(wc), ptr(dx), ptr(dw), ptr(db), int(relu),
                                         dropout_p, ptr(ws), ws.numel(), B, K, N, DTYPE_CODE[T], stream()), "emb_linear_bwd")
         cast = lambda g, d: None if g is None else (g if g.dtype == d else g.to(d))
