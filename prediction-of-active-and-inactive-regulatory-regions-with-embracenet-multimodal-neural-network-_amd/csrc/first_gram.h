@@ -236,8 +236,11 @@ namespace emb {
 
 constexpr int kGramUsed = kGramEdgeS + 2 * kGramEdge * 4;   // floats of a totals row in use
 constexpr int kFinFixed = kGramUsed + 4 + 128 + 128 + 4;   // floats of LDS before As
+static_assert(kFinFixed % 4 == 0, "As must start on a 16-byte boundary (vector stores of the slab sum)");
 constexpr int kFinCols = 64;                       // floats per slab row of the accumulate pass: 4 k compact columns + sum of g, k <= 15
-template <int NTHR> constexpr int first_finish_lds_floats() { return kFinFixed + NTHR; }
+// slice groups of the finish's slab sum: NTHR / 64 threads per column (1024 threads: 16), or NTHR / 16 per four columns (fewer)
+template <int NTHR> constexpr int first_finish_groups() { return NTHR >= 1024 ? NTHR / kFinCols : NTHR / 16; }
+template <int NTHR> constexpr int first_finish_lds_floats() { return kFinFixed + first_finish_groups<NTHR>() * kFinCols; }
 
 // The per-channel finish of the recompute-free backward (top of this file): channel c, NTHR threads (a multiple of 128), `lds`
 // = first_finish_lds_floats<NTHR>() floats.  Results go to `sink`: sink.scalars(dgamma, dbeta, dbias) once (thread 0) and
@@ -245,7 +248,7 @@ template <int NTHR> constexpr int first_finish_lds_floats() { return kFinFixed +
 // stores them, the optimizer launch (loss_optim.hip) updates the parameters with them on the spot.
 template <int NTHR, typename Sink>
 __device__ __forceinline__ void first_finish_body(const FirstFinArgs& a, const int c, float* lds, Sink&& sink) {
-  constexpr int NG = NTHR / kFinCols, NPd = kGramMaxK * 16;   // slice groups of the slab sum; (d, c1, c2) entries per edge position
+  constexpr int NG = first_finish_groups<NTHR>(), NPd = kGramMaxK * 16;   // slice groups of the slab sum; (d, c1, c2) entries per edge position
   float* G0 = lds + kGramG0;                              // the totals row, verbatim: G0 [4][128],
   float* PP = lds + kGramP;                               // [2][7][15][16] P totals -> inclusive prefix sums over the edge position,
   float* ES = lds + kGramEdgeS;                           // [2][7][4] edge sums -> inclusive prefix sums
@@ -266,7 +269,8 @@ __device__ __forceinline__ void first_finish_body(const FirstFinArgs& a, const i
   } else {
     for (int i = tid; i < kGramUsed; i += NTHR) lds[i] = a.gram[i];
   }
-  {   // A[c][n'] = sum over the slices (compact columns n' = tap * 4 + ci, 4 k = sum of g; kFinCols per slab row): NG slice groups
+  if constexpr (WIDE) {
+      // A[c][n'] = sum over the slices (compact columns n' = tap * 4 + ci, 4 k = sum of g; kFinCols per slab row): NG slice groups
       // x 64 columns, NIF loads in flight, the groups meet in group order
     const int m = tid & (kFinCols - 1), sgp = tid / kFinCols;
     float s = 0.0f;
@@ -284,6 +288,26 @@ __device__ __forceinline__ void first_finish_body(const FirstFinArgs& a, const i
       for (; i < a.S; i += NG) s += src[(long)i * stride];
     }
     As[sgp * kFinCols + m] = s;
+  } else {
+    // the same sum with 16-byte loads: thread (slice group, four columns), NG = NTHR / 16 groups -- at S = 256 slices and 256
+    // threads every thread holds 16 slices, two rounds of eight loads (one column per thread: 64 slices, eight dependent rounds,
+    // the critical path of the optimizer launch this finish rides in)
+    const int cg = tid & 15, sgp = tid >> 4;
+    f32x4 s = {0.f, 0.f, 0.f, 0.f};
+    if (4 * cg <= 4 * k) {
+      const float* src = a.slab + (long)c * kFinCols + 4 * cg;
+      const long stride = (long)a.C * kFinCols;
+      int i = sgp;
+      for (; i + (NIF - 1) * NG < a.S; i += NIF * NG) {
+        f32x4 v[NIF];
+#pragma unroll
+        for (int j = 0; j < NIF; ++j) v[j] = *reinterpret_cast<const f32x4*>(src + (long)(i + j * NG) * stride);
+#pragma unroll
+        for (int j = 0; j < NIF; ++j) s += v[j];
+      }
+      for (; i < a.S; i += NG) s += *reinterpret_cast<const f32x4*>(src + (long)i * stride);
+    }
+    *reinterpret_cast<f32x4*>(As + sgp * kFinCols + 4 * cg) = s;
   }
   if (WIDE) {
 #pragma unroll

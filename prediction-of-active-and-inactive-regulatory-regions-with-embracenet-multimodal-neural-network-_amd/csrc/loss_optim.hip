@@ -540,7 +540,7 @@ __global__ __launch_bounds__(256) void multi_opt_kernel(const MultiArgs<P> args,
 
   if constexpr (sizeof(P) == 4) {
     if (bid < 0) {            // finish of the first conv block's backward for channel blockIdx.x, parameters updated on the spot
-      __shared__ float fin_lds[first_finish_lds_floats<256>()];
+      __shared__ __attribute__((aligned(16))) float fin_lds[first_finish_lds_floats<256>()];
       struct Sink {
         const MultiArgs<P>& a;
         const OptConst<P>& kc;

@@ -68,7 +68,7 @@ struct FinStoreR {
 template <typename P> __global__ __launch_bounds__(256) void multi_reduce_kernel(const ReduceTable tab, const FirstFinArgs fin, const int nfin) {
   if constexpr (sizeof(P) == 4) {
     if ((int)blockIdx.x < nfin) {
-      __shared__ float fin_lds[first_finish_lds_floats<256>()];
+      __shared__ __attribute__((aligned(16))) float fin_lds[first_finish_lds_floats<256>()];
       first_finish_body<256>(fin, (int)blockIdx.x, fin_lds, FinStoreR{fin, (int)blockIdx.x});
       return;
     }
