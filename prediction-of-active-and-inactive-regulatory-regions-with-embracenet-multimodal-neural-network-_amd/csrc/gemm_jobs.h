@@ -73,6 +73,7 @@ struct GArgs {
 struct GTile {
   int valid, kind;
   int m0, n0, k_begin, k_end, nstages;
+  int st0;              // first stage of the reduction this group of waves multiplies (kind 2: stage -> (tap, channel block))
   int M, N, lda, ldb, ldc, S;
   const char *A, *Bm;
   char* C;
@@ -106,6 +107,7 @@ __device__ __forceinline__ GTile gj_decode(int id, gj_args_ptr ka) {
   t.k_begin = slice * j.kper;
   t.k_end = min(j.K, t.k_begin + j.kper);
   t.nstages = (t.k_end - t.k_begin + kGjKC - 1) / kGjKC;
+  t.st0 = 0;
   t.M = j.M; t.N = j.N; t.lda = j.lda; t.ldb = j.ldb; t.ldc = j.ldc; t.S = j.S;
   t.A = j.A; t.Bm = j.Bm;
   t.C = j.C + (long)slice * j.slice_stride;
@@ -188,14 +190,15 @@ __device__ __forceinline__ void gj_feed_tile(GFeed& f, const GTile& t, int lane,
     const int slot = 16 * ((lane & 7) ^ swz16((int)row));
     f.ra = gj_make_rsrc(t.A, (long)t.R * t.cin * 4);
     f.rb = gj_make_rsrc(t.Bm + (long)t.n0 * t.ldb * 4, (long)(t.N - t.n0) * t.ldb * 4);
-    f.tap = 0; f.cb = 0; f.cpt = t.cin / 32; f.L = t.L; f.pad = t.pad; f.cin4 = t.cin * 4;
+    f.cpt = t.cin / 32; f.L = t.L; f.pad = t.pad; f.cin4 = t.cin * 4;
+    f.tap = t.st0 / f.cpt; f.cb = t.st0 - f.tap * f.cpt;
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
       const int r = t.m0 + (int)row + 64 * i;
       const int b = r / t.L;
       f.lpos[i] = r < t.R ? r - b * t.L : -(1 << 24);
       f.cbase[i] = (uint32_t)r * (uint32_t)(t.cin * 4) + (uint32_t)slot;
-      f.off[2 + i] = (row + 64u * i) * (uint32_t)(t.ldb * 4) + (uint32_t)slot;
+      f.off[2 + i] = (row + 64u * i) * (uint32_t)(t.ldb * 4) + (uint32_t)slot + (uint32_t)t.st0 * 128u;
       f.dst[i] = (uint32_t)(i * 8192 + wave * 1024);
       f.dst[2 + i] = (uint32_t)(16384 + i * 8192 + wave * 1024);
     }
@@ -323,19 +326,38 @@ struct GHalf {                                    // fragments of one half of a 
   float b[2][4];                                  // m side: [row tile][step j]
 };
 
-template <int SLOTS>
-__global__ __launch_bounds__(kGjThreads, SLOTS == 2 ? 4 : 2) void gemm_jobs_kernel(const GArgs args) {
+// PAIR: sixteen waves; waves 8-15 are a second group that multiplies the SECOND HALF of the tile's reduction on the same 128 x 128
+// tile with its own two-slot ring (the two-slot schedule, 4 waves per SIMD inside ONE workgroup: the matrix pipe stays fed whatever
+// the number of tiles of the launch, and the longest tile's critical path halves); the two accumulator sets meet through LDS in
+// fixed order (first half + second half) before the epilogue, which the first group runs.
+template <int SLOTS, bool PAIR>
+__global__ __launch_bounds__(PAIR ? 2 * kGjThreads : kGjThreads, SLOTS == 2 ? 4 : 2) void gemm_jobs_kernel(const GArgs args) {
 #if defined(__HIP_DEVICE_COMPILE__)
+  static_assert(!PAIR || SLOTS == 2, "the paired groups run the two-slot schedule");
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const gj_args_ptr ka = (gj_args_ptr)__builtin_amdgcn_kernarg_segment_ptr();
-  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int lane = threadIdx.x & 63, wave16 = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int wave = wave16 & 7, sub = wave16 >> 3;    // group of eight waves (PAIR: 0 / 1)
   const int wr = wave >> 1, wc = wave & 1;           // this wave: m rows 32 wr .. +32, n columns 64 wc .. +64
-  const uint32_t lds0 = (uint32_t)(uintptr_t)smem;
+  const uint32_t lds0 = (uint32_t)(uintptr_t)smem + (uint32_t)(sub * SLOTS * kGjStage);
   EMB_STAMP(2);
   // ONE tile per workgroup, in list order = longest first: the hardware's workgroup dispatcher is the load balancer (a tile
   // of the input gradient multiplies c / 32 stages, a weight-gradient slice kper / 32; dealt out statically the workgroups that
   // drew two long tiles ran alone at the end -- measured 142 us against 99 us at the cfg3 shapes)
-  const GTile t = gj_decode(blockIdx.x, ka);
+  GTile t = gj_decode(blockIdx.x, ka);
+  int iters = t.nstages;                             // barrier intervals of the main loop (the same for all waves of the workgroup)
+  if constexpr (PAIR) {
+    const int n0s = (t.nstages + 1) >> 1;            // stages of the first group (the longer half)
+    iters = n0s;
+    if (sub == 0) {
+      t.k_end = min(t.k_end, t.k_begin + n0s * kGjKC);
+      t.nstages = n0s;
+    } else {
+      t.k_begin += n0s * kGjKC;
+      t.st0 = n0s;
+      t.nstages -= n0s;
+    }
+  }
   GFeed feed;
   feed.slot = 0;
   gj_feed_tile(feed, t, lane, wave);
@@ -461,12 +483,13 @@ __global__ __launch_bounds__(kGjThreads, SLOTS == 2 ? 4 : 2) void gemm_jobs_kern
       // issued under the first half's fragment reads, the other two (and the second half's reads) after the first MFMA group
       // (three quarters of a stage left to land)
 #pragma unroll 1
-      for (int s = 0; s < t.nstages; ++s) {
+      for (int s = 0; s < iters; ++s) {
         EMB_WAIT_VMCNT(0);
 #ifndef GJ_DIAG_NO_BARRIER
         __builtin_amdgcn_s_barrier();
 #endif
         asm volatile("" ::: "memory");
+        if (PAIR && s >= t.nstages) continue;        // (the second group of an odd number of stages sits the last interval out)
 #ifdef GJ_DIAG_NO_DMA
         const bool feeding = false;
 #else
@@ -533,6 +556,31 @@ __global__ __launch_bounds__(kGjThreads, SLOTS == 2 ? 4 : 2) void gemm_jobs_kern
     }
 #undef GJ_MMA
     EMB_STAMP(5);
+    if constexpr (PAIR) {
+      // the second group's accumulators (and bias-gradient shares) cross to the first through LDS: [wave][vector][lane] 16 bytes
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();                                 // both rings are idle
+      f32x4* xch = reinterpret_cast<f32x4*>(smem);
+      float* xsb = reinterpret_cast<float*>(smem + 8 * 8 * 64 * 16);
+      if (sub == 1) {
+#pragma unroll
+        for (int mi = 0; mi < 2; ++mi) {
+#pragma unroll
+          for (int ni = 0; ni < 4; ++ni) xch[(wave * 8 + mi * 4 + ni) * 64 + lane] = acc[ni][mi];
+          xsb[(wave * 2 + mi) * 64 + lane] = sb[mi];
+        }
+      }
+      __syncthreads();
+      if (sub == 0) {
+#pragma unroll
+        for (int mi = 0; mi < 2; ++mi) {
+#pragma unroll
+          for (int ni = 0; ni < 4; ++ni) acc[ni][mi] += xch[(wave * 8 + mi * 4 + ni) * 64 + lane];
+          sb[mi] += xsb[(wave * 2 + mi) * 64 + lane];
+        }
+      }
+    }
+    const bool storing = !PAIR || sub == 0;            // (the second group still takes part in the epilogue's barriers)
     // the tile leaves from registers.  Accumulator (ni, mi) of lane (r, g): row 32 wr + 16 mi + r, columns 64 wc + 16 ni + 4 g .. + 3.
     {
       const long rem = (((long)t.M - t.m0) * t.ldc - t.n0) * 4;                   // rows >= M are dropped by the range check
@@ -566,7 +614,7 @@ __global__ __launch_bounds__(kGjThreads, SLOTS == 2 ? 4 : 2) void gemm_jobs_kern
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();                                             // every stage has been multiplied: the ring is free
         float* red = reinterpret_cast<float*>(smem);                              // [4 wave rows][2][128 channels]
-        if (r == 0) {
+        if (r == 0 && storing) {
 #pragma unroll
           for (int ni = 0; ni < 4; ++ni)
 #pragma unroll
@@ -584,18 +632,20 @@ __global__ __launch_bounds__(kGjThreads, SLOTS == 2 ? 4 : 2) void gemm_jobs_kern
                 ((red[(0 * 2 + which) * 128 + ch] + red[(1 * 2 + which) * 128 + ch]) + red[(2 * 2 + which) * 128 + ch]) + red[(3 * 2 + which) * 128 + ch];
         }
       }
+      if (storing) {
 #pragma unroll
-      for (int mi = 0; mi < 2; ++mi) {
-        const uint32_t rowoff = (uint32_t)(wr * 32 + mi * 16 + r) * (uint32_t)t.ldc;
+        for (int mi = 0; mi < 2; ++mi) {
+          const uint32_t rowoff = (uint32_t)(wr * 32 + mi * 16 + r) * (uint32_t)t.ldc;
 #pragma unroll
-        for (int ni = 0; ni < 4; ++ni) {
-          const int ncol = wc * 64 + ni * 16 + 4 * g;
-          const bool inside = t.n0 + ncol < t.N;                                  // N % 4 == 0: four columns are inside together
-          __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, acc[ni][mi]), rs,
-                                                 inside ? (rowoff + (uint32_t)ncol) * 4u : kDmaInvalid, 0, 0);
+          for (int ni = 0; ni < 4; ++ni) {
+            const int ncol = wc * 64 + ni * 16 + 4 * g;
+            const bool inside = t.n0 + ncol < t.N;                                // N % 4 == 0: four columns are inside together
+            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, acc[ni][mi]), rs,
+                                                   inside ? (rowoff + (uint32_t)ncol) * 4u : kDmaInvalid, 0, 0);
+          }
         }
       }
-      if (with_bias) {                                                            // db[m] = sum over the four lane groups' k shares
+      if (with_bias && storing) {                                                            // db[m] = sum over the four lane groups' k shares
 #pragma unroll
         for (int mi = 0; mi < 2; ++mi) {
           float sum = sb[mi];
@@ -614,10 +664,13 @@ __global__ __launch_bounds__(kGjThreads, SLOTS == 2 ? 4 : 2) void gemm_jobs_kern
 #endif
 }
 
-// One tile per workgroup.  With enough tiles for two workgroups on every CU the two-slot kernel runs (64 KB of LDS each): four
-// waves per SIMD keep the fp32 matrix pipe fed through each other's barriers, fragment reads and DMA issue (two waves of ONE
-// workgroup leave it idle ~30 % of the loop, tools/kbench variants), and a workgroup's set-up and stores run under its
-// neighbour's main loop.  Fewer tiles: one workgroup per CU, five slots, four stages requested ahead.
+// One tile per workgroup.  The matrix pipe needs FOUR waves per SIMD to stay fed through barriers, fragment reads and DMA issue:
+// two waves of one workgroup leave it idle ~30 % of the main loop whatever their schedule (tools/kbench timing variants: every
+// ingredient costs its full duration on top of the MFMAs; running the two halves of the workgroup half a stage apart changed
+// nothing), two independent workgroups per CU reach ~4450 cycles per stage and CU against 4480 of matrix work.
+//   many tiles (more than 1.25 per CU): the two-slot kernel, 64 KB of LDS, two workgroups per CU -- a workgroup's set-up and stores
+//     also run under its neighbour's main loop;
+//   fewer: the PAIRED kernel, sixteen waves on one tile, each group of eight multiplying one half of the reduction (128 KB of LDS).
 static int gj_cus() {
   static const int cus = [] {
     int dev = 0, v = 256;
@@ -630,17 +683,19 @@ static void gj_launch(const GArgs& ga, int n, hipStream_t s) {
   const int cus = gj_cus();
   static bool attr_set = false;
   if (!attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_jobs_kernel<5>), hipFuncAttributeMaxDynamicSharedMemorySize, kGjLds<5>);
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_jobs_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, kGjLds<2>);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_jobs_kernel<5, false>), hipFuncAttributeMaxDynamicSharedMemorySize, kGjLds<5>);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_jobs_kernel<2, false>), hipFuncAttributeMaxDynamicSharedMemorySize, kGjLds<2>);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_jobs_kernel<2, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * kGjLds<2>);
     attr_set = true;
   }
 #ifdef GJ_DIAG_FORCE_SLOTS
-  const bool two = GJ_DIAG_FORCE_SLOTS == 2;
+  const int mode = GJ_DIAG_FORCE_SLOTS;              // 2: two-slot, 5: five-slot (one workgroup per CU, eight waves), 16: paired
 #else
-  const bool two = n > cus + cus / 4;
+  const int mode = n > cus + cus / 4 ? 2 : 16;
 #endif
-  if (two) gemm_jobs_kernel<2><<<n, kGjThreads, kGjLds<2>, s>>>(ga);
-  else gemm_jobs_kernel<5><<<n, kGjThreads, kGjLds<5>, s>>>(ga);
+  if (mode == 2) gemm_jobs_kernel<2, false><<<n, kGjThreads, kGjLds<2>, s>>>(ga);
+  else if (mode == 5) gemm_jobs_kernel<5, false><<<n, kGjThreads, kGjLds<5>, s>>>(ga);
+  else gemm_jobs_kernel<2, true><<<n, 2 * kGjThreads, 2 * kGjLds<2>, s>>>(ga);
 }
 
 // returns 1 when the shapes do not qualify (the caller keeps its other kernels)
