@@ -1,30 +1,32 @@
-// Persistent ring GEMM: the EmbraceNet backward on PRE-MASKED gradients, fp32 (v_mfma_f32_16x16x4_f32).
+// fp32 tile GEMM on LDS-DMA stages (v_mfma_f32_16x16x4_f32): the EmbraceNet backward on PRE-MASKED gradients, the backward of large
+// Linear layers, and the convolutions of the stored-activation blocks with >= 128 output channels.
 //
 //   dX_m[B,d_m] = dD_m   W_m      "dgrad"  A = dD_m row-major [M = B][K = c],  Bm = W_m K-major [c][d_m]
 //   dW_m[c,d_m] = dD_m^T X_m      "wgrad"  A = dD_m K-major  [K = B][M = c],   Bm = X_m K-major [B][d_m]   (+ db_m = sum_b dD_m)
 // with dD_m = dE * [idx == m] * [pre_m > 0] written ONCE by the kernel that produces dE (the classifier head, head.hip, or
 // emb_embrace_premask) instead of being re-derived from dE and the code bytes by every wave for every fragment: the four jobs are
 // plain GEMMs.  fp32 is the precision the 1e-5 parity bar is stated in and BASELINE configs 3 and 4 run in; its matrix rate is
-// 1/16 of bf16's, so this path is bound by the MATRIX PIPE once the operands arrive on time -- which is what the ring is for.
-// (The same structure was built and measured for bf16 first: there the per-stage bookkeeping of a 64-deep stage -- barrier,
-// scalar control flow, exposed LDS latency, ~150 cycles of issue per LDS-DMA instruction -- cost more than its 16 MFMAs, 12.2 us
-// against 9.7 us for embrace_bwd_split.h at cfg2, so bf16 keeps that kernel.)
+// 1/16 of bf16's, so this path is bound by the MATRIX PIPE once the operands arrive on time.
 // Replaces autograd through EmbraceNetMultimodal.py:52-60,80-88 (utils/training_models_multimodal.py:156, :115 "model.double()":
 // the reference trains in fp64; fp32 is the engine's exact-parity precision).
 //
-// Structure.  One PERSISTENT workgroup per CU (8 waves as 4 x 2, two per SIMD) walks a static list of 128 x 128 output tiles of
-// all four jobs (list position v = workgroup + i * grid, XCD-aware order).  All operand traffic of a workgroup is ONE stream of
-// 32 KB stages (32 reduction indices of a tile: m-side image 16 KB + n-side image 16 KB) through a ring of five LDS slots,
-// requested by LDS-DMA four stages ahead of the stage being multiplied -- across tile boundaries: while a tile's last stages
-// are multiplied and its accumulators leave, the next tile's first stages are already landing.  One raw s_barrier per stage
-// (64 MFMAs = 2048 matrix-pipe cycles per wave); a wave waits for its own four DMA instructions of a stage by a counted vmcnt;
-// the fragments of a stage's first half are read while the previous stage's second half is multiplied.  Finished accumulators go
-// to memory straight from registers (buffer stores: the range check drops rows past the matrix; 16 bytes per lane, four adjacent
-// column tiles complete every 256-byte row segment) and overlap the next tile's multiplies.
+// Structure.  One workgroup per 128 x 128 output tile, tiles in list order = longest first (the hardware dispatcher is the load
+// balancer).  A group of eight waves (4 x 2, each 32 rows x 64 columns) streams its operands as 32 KB stages (32 reduction
+// indices: m-side image 16 KB + n-side image 16 KB) through a DOUBLE BUFFER in LDS, each stage requested by LDS-DMA (issued from
+// inline assembly, see gj_dma) while the previous one is multiplied: one raw s_barrier per stage makes the stage visible and
+// frees the other slot.  Accumulators leave straight from registers (buffer stores, 16 bytes per lane; the range check drops rows
+// past the matrix).
+// What feeds the matrix pipe is FOUR waves per SIMD (measured, tools/kbench: two waves per SIMD leave it idle ~30 % of the loop
+// whatever their schedule -- a five-slot ring requested four stages ahead, the next stage's fragments read ahead, the two halves of
+// the workgroup running half a stage apart: every variant stayed at ~6300 cycles per stage against 4480 of matrix work):
+//   - launches with many tiles: 512-thread workgroups, 64 KB of LDS, TWO per CU;
+//   - launches with few tiles (gj_launch): 1024-thread workgroups whose two groups of eight waves multiply the two HALVES of the
+//     tile's reduction, each through its own double buffer; the second group's accumulators cross to the first through LDS (fixed
+//     order: first half + second half) before the epilogue.  This also halves the critical path of a long tile.
 // Images.  Row-major operand (dgrad m side): 128 rows x 128 B (32 k).  K-major operands: four QUARTER images of 32 k rows x
 // 128 B (32 columns) each.  All rows are 128 bytes with their eight 16-byte slots XOR-permuted by swz16(row) (split_core.h):
 // the permutation is applied to the per-lane source address of the (lane-linear) LDS-DMA and again in the fragment reads.
-// MFMA step (h, j), h = 0..1, j = 0..3: lane group g supplies k = 16 h + 4 g + j on both operands -- the row-major operand
+// MFMA step (h, j), h = 0..1, j = 0..3: lane group g supplies k = 16 h + 4 kq(g) + j on both operands -- the row-major operand
 // with ONE ds_read_b128 per (tile, h) (its four floats are the four j), the K-major operands with one ds_read_b32 per step.
 #pragma once
 #include "conv_tiles.h"
@@ -36,9 +38,8 @@ constexpr int kGjThreads = 512;
 constexpr int kGjKC = 32;                         // reduction indices per stage
 constexpr int kGjStage = 32 * 1024;               // m-side image (16 KB) + n-side image (16 KB)
 constexpr int kGjDma = 4;                         // LDS-DMA instructions per wave and stage
-// ring depth, a template parameter of the kernel: 5 slots (160 KB: one workgroup per CU, four stages requested ahead) or 2 slots
-// (64 KB: TWO workgroups per CU, one stage ahead)
-template <int SLOTS> constexpr int kGjLds = SLOTS * kGjStage;
+constexpr int kGjSlots = 2;                       // double buffer: the stage being multiplied and the one in flight
+constexpr int kGjLds = kGjSlots * kGjStage;       // 64 KB per group of eight waves
 
 struct GJob {
   const char* A;        // m-side operand (pre-masked gradient)
@@ -117,13 +118,13 @@ __device__ __forceinline__ GTile gj_decode(int id, gj_args_ptr ka) {
   return t;
 }
 
-// The request side of the ring.  Per tile: two buffer resources whose bases are the tile's first stage (their range checks
+// The request side.  Per tile: two buffer resources whose bases are the tile's first stage (their range checks
 // zero-fill everything past the operands: rows >= M, reduction indices >= k_end, columns >= N via invalid lane offsets), and
 // this wave's four per-lane byte offsets; per stage: four LDS-DMA instructions and four vector adds (offsets of lanes that
 // must read zeros start at 2^31 and stay out of range).
 // LDS-DMA is issued from inline assembly: the compiler orders every LDS read behind ALL outstanding `buffer_load ... lds` it
 // knows of (s_waitcnt vmcnt(0)), which would serialise the stages in flight (measured: 2200 cycles per stage instead of ~600);
-// every consumer of the ring waits explicitly (gj_wait + s_barrier).
+// every consumer of a stage waits explicitly (s_waitcnt vmcnt(0) + s_barrier).
 typedef int gj_rsrc __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ gj_rsrc gj_make_rsrc(const void* origin, long bytes) {
   const uint64_t p = (uint64_t)(uintptr_t)origin;
@@ -266,7 +267,7 @@ __device__ __forceinline__ void gj_feed_tile(GFeed& f, const GTile& t, int lane,
 // takes 64 B per clock, 32 KB per stage = 512 cycles per CU), which hides under the other waves' MFMAs only when the eight
 // waves do not all issue at once right after the barrier.
 __device__ __forceinline__ bool gj_more(const GFeed& f) { return f.stage < f.nstages; }
-template <int I, int SLOTS> __device__ __forceinline__ void gj_part(GFeed& f, uint32_t lds0) {
+template <int I> __device__ __forceinline__ void gj_part(GFeed& f, uint32_t lds0) {
   constexpr int IA = I < 2 ? I : 0, IB = I >= 2 ? I - 2 : 0;   // (in-range indices for the branches I does not take)
   const uint32_t buf = lds0 + (uint32_t)(f.slot * kGjStage) + f.dst[I];
   if (f.kind == 2 && I < 2) {                      // activation rows shifted by the stage's tap
@@ -286,7 +287,7 @@ template <int I, int SLOTS> __device__ __forceinline__ void gj_part(GFeed& f, ui
       if (l >= f.L) l -= f.L;
       if (l >= f.L) l -= f.L;
       f.lpos[0] = l;
-      f.slot = f.slot + 1 == SLOTS ? 0 : f.slot + 1;
+      f.slot ^= 1;
       ++f.stage;
     }
     return;
@@ -301,25 +302,16 @@ template <int I, int SLOTS> __device__ __forceinline__ void gj_part(GFeed& f, ui
     f.off[I] += f.step_b;
   }
   if (I == 3) {
-    f.slot = f.slot + 1 == SLOTS ? 0 : f.slot + 1;
+    f.slot ^= 1;
     ++f.stage;
   }
 }
-template <int SLOTS> __device__ __forceinline__ bool gj_request(GFeed& f, uint32_t lds0) {
+__device__ __forceinline__ bool gj_request(GFeed& f, uint32_t lds0) {
   if (!gj_more(f)) return false;
-  gj_part<0, SLOTS>(f, lds0); gj_part<1, SLOTS>(f, lds0); gj_part<2, SLOTS>(f, lds0); gj_part<3, SLOTS>(f, lds0);
+  gj_part<0>(f, lds0); gj_part<1>(f, lds0); gj_part<2>(f, lds0); gj_part<3>(f, lds0);
   return true;
 }
 #endif
-
-// wait until this wave's DMA instructions of a stage have landed: `younger` later stages (0 .. 3) may stay in flight.
-// Accumulator stores of a finished tile are younger still and only make the wait conservative.
-__device__ __forceinline__ void gj_wait(int younger) {
-  if (younger >= 3) EMB_WAIT_VMCNT(3 * kGjDma);
-  else if (younger == 2) EMB_WAIT_VMCNT(2 * kGjDma);
-  else if (younger == 1) EMB_WAIT_VMCNT(kGjDma);
-  else EMB_WAIT_VMCNT(0);
-}
 
 struct GHalf {                                    // fragments of one half of a stage (16 reduction indices = 4 MFMA steps)
   float a[4][4];                                  // n side: [column tile][step j]
@@ -330,16 +322,15 @@ struct GHalf {                                    // fragments of one half of a 
 // tile with its own two-slot ring (the two-slot schedule, 4 waves per SIMD inside ONE workgroup: the matrix pipe stays fed whatever
 // the number of tiles of the launch, and the longest tile's critical path halves); the two accumulator sets meet through LDS in
 // fixed order (first half + second half) before the epilogue, which the first group runs.
-template <int SLOTS, bool PAIR>
-__global__ __launch_bounds__(PAIR ? 2 * kGjThreads : kGjThreads, SLOTS == 2 ? 4 : 2) void gemm_jobs_kernel(const GArgs args) {
+template <bool PAIR>
+__global__ __launch_bounds__(PAIR ? 2 * kGjThreads : kGjThreads, 4) void gemm_jobs_kernel(const GArgs args) {
 #if defined(__HIP_DEVICE_COMPILE__)
-  static_assert(!PAIR || SLOTS == 2, "the paired groups run the two-slot schedule");
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const gj_args_ptr ka = (gj_args_ptr)__builtin_amdgcn_kernarg_segment_ptr();
   const int lane = threadIdx.x & 63, wave16 = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int wave = wave16 & 7, sub = wave16 >> 3;    // group of eight waves (PAIR: 0 / 1)
   const int wr = wave >> 1, wc = wave & 1;           // this wave: m rows 32 wr .. +32, n columns 64 wc .. +64
-  const uint32_t lds0 = (uint32_t)(uintptr_t)smem + (uint32_t)(sub * SLOTS * kGjStage);
+  const uint32_t lds0 = (uint32_t)(uintptr_t)smem + (uint32_t)(sub * kGjLds);
   EMB_STAMP(2);
   // ONE tile per workgroup, in list order = longest first: the hardware's workgroup dispatcher is the load balancer (a tile
   // of the input gradient multiplies c / 32 stages, a weight-gradient slice kper / 32; dealt out statically the workgroups that
@@ -361,10 +352,7 @@ __global__ __launch_bounds__(PAIR ? 2 * kGjThreads : kGjThreads, SLOTS == 2 ? 4 
   GFeed feed;
   feed.slot = 0;
   gj_feed_tile(feed, t, lane, wave);
-  int requested = 0;                                 // stages requested so far
-#pragma unroll 1
-  for (int i = 0; i < SLOTS - 1; ++i) requested += gj_request<SLOTS>(feed, lds0) ? 1 : 0;
-  requested = __builtin_amdgcn_readfirstlane(requested);
+  (void)gj_request(feed, lds0);                      // stage 0
   EMB_STAMP(3);
 
   // per-lane parts of the fragment reads (tile-independent).  MFMA step (h, j): lane group g supplies k = 16 h + 4 kq(g) + j with
@@ -439,14 +427,7 @@ __global__ __launch_bounds__(PAIR ? 2 * kGjThreads : kGjThreads, SLOTS == 2 ? 4 
 
   int slot = 0;
   GHalf f0, f1;
-  if constexpr (SLOTS > 2) {
-    // stage 0: visible after this barrier; its first half's fragments are read ahead of the loop
-    gj_wait(requested - 1);
-    __builtin_amdgcn_s_barrier();
-    asm volatile("" ::: "memory");
-  }
   EMB_STAMP(4);
-  if constexpr (SLOTS > 2) load(lds0, t.kind, 0, f0);
 #ifdef GJ_DIAG_NO_LOAD
   load(lds0, t.kind, 0, f0);
   load(lds0, t.kind, 1, f1);
@@ -476,8 +457,8 @@ __global__ __launch_bounds__(PAIR ? 2 * kGjThreads : kGjThreads, SLOTS == 2 ? 4 
       }                                                                                                                      \
       __builtin_amdgcn_sched_barrier(0)
 #endif
-    if constexpr (SLOTS == 2) {
-      // two workgroups per CU (four waves per SIMD): the other workgroup's MFMAs fill this one's barrier, LDS-latency and
+    {
+      // two workgroups per CU, or two groups of eight waves in one (four waves per SIMD): the other workgroup's MFMAs fill this one's barrier, LDS-latency and
       // DMA-issue phases, so the schedule is the plain double buffer: the stage is visible after the barrier, which also frees
       // the other slot (every wave has multiplied the previous stage) for the next request; its first two DMA instructions are
       // issued under the first half's fragment reads, the other two (and the second half's reads) after the first MFMA group
@@ -500,59 +481,16 @@ __global__ __launch_bounds__(PAIR ? 2 * kGjThreads : kGjThreads, SLOTS == 2 ? 4 
 #ifndef GJ_DIAG_NO_LOAD
         load(buf, t.kind, 0, f0);
 #endif
-        if (feeding) { gj_part<0, SLOTS>(feed, lds0); gj_part<1, SLOTS>(feed, lds0); }
+        if (feeding) { gj_part<0>(feed, lds0); gj_part<1>(feed, lds0); }
         GJ_MMA(f0, 0);
 #ifndef GJ_DIAG_NO_LOAD
         load(buf, t.kind, 1, f1);
 #endif
-        if (feeding) { gj_part<2, SLOTS>(feed, lds0); gj_part<3, SLOTS>(feed, lds0); }
+        if (feeding) { gj_part<2>(feed, lds0); gj_part<3>(feed, lds0); }
         GJ_MMA(f0, 2);
         GJ_MMA(f1, 0);
         GJ_MMA(f1, 2);
       }
-    } else {
-    // waves w and w + 4 share a SIMD: the second half issues each DMA instruction one MFMA group EARLIER than its partner, so
-    // that one of the two is multiplying while the other sits in the ~150 cycles an LDS-DMA instruction takes to issue
-    const bool early = wave >= 4;
-#pragma unroll 1
-    for (int s = 0; s < t.nstages; ++s) {
-      const bool more = s + 1 < t.nstages;           // another stage follows this one
-      // make the next stage visible (its fragments are read while this stage's second half is multiplied); every wave
-      // has then also finished the stage multiplied before this one: its slot takes the next request
-      if (more) gj_wait(requested - s - 2);
-#ifndef GJ_DIAG_NO_BARRIER
-      __builtin_amdgcn_s_barrier();                  // raw barrier: a __syncthreads() would drain the younger stages
-#endif
-      asm volatile("" ::: "memory");
-#ifdef GJ_DIAG_NO_DMA
-      const bool feeding = false;
-#else
-      const bool feeding = gj_more(feed);
-#endif
-      requested += feeding ? 1 : 0;
-      if (feeding && early) gj_part<0, SLOTS>(feed, lds0);
-      const uint32_t buf = lds0 + (uint32_t)(slot * kGjStage);
-      slot = slot + 1 == SLOTS ? 0 : slot + 1;
-      const uint32_t nbuf = lds0 + (uint32_t)(slot * kGjStage);
-#ifndef GJ_DIAG_NO_LOAD
-      load(buf, t.kind, 1, f1);
-#endif
-      GJ_MMA(f0, 0);
-      if (feeding) { if (early) gj_part<1, SLOTS>(feed, lds0); else gj_part<0, SLOTS>(feed, lds0); }
-      GJ_MMA(f0, 2);
-      if (feeding) { if (early) gj_part<2, SLOTS>(feed, lds0); else gj_part<1, SLOTS>(feed, lds0); }
-#ifndef GJ_DIAG_NO_LOAD
-      if (more) load(nbuf, t.kind, 0, f0);
-#endif
-      GJ_MMA(f1, 0);
-      if (feeding) { if (early) gj_part<3, SLOTS>(feed, lds0); else gj_part<2, SLOTS>(feed, lds0); }
-      GJ_MMA(f1, 2);
-      if (feeding && !early) gj_part<3, SLOTS>(feed, lds0);
-      // the compiler's wait-count model gives up on LDS reads that are pending across the loop edge (it would wait for
-      // everything, the reads just issued included, before the next iteration's first MFMA): pin the arrival of f0 here
-      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-      asm volatile("" : : "v"(f0.a[0][0]), "v"(f0.a[1][1]), "v"(f0.a[2][2]), "v"(f0.a[3][3]), "v"(f0.b[0][0]), "v"(f0.b[1][3]));
-    }
     }
 #undef GJ_MMA
     EMB_STAMP(5);
@@ -683,19 +621,17 @@ static void gj_launch(const GArgs& ga, int n, hipStream_t s) {
   const int cus = gj_cus();
   static bool attr_set = false;
   if (!attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_jobs_kernel<5, false>), hipFuncAttributeMaxDynamicSharedMemorySize, kGjLds<5>);
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_jobs_kernel<2, false>), hipFuncAttributeMaxDynamicSharedMemorySize, kGjLds<2>);
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_jobs_kernel<2, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * kGjLds<2>);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_jobs_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, kGjLds);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_jobs_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * kGjLds);
     attr_set = true;
   }
-#ifdef GJ_DIAG_FORCE_SLOTS
-  const int mode = GJ_DIAG_FORCE_SLOTS;              // 2: two-slot, 5: five-slot (one workgroup per CU, eight waves), 16: paired
+#ifdef GJ_DIAG_FORCE_MODE
+  const bool paired = GJ_DIAG_FORCE_MODE == 16;      // (tools/kbench: 2 = eight waves per tile, 16 = paired)
 #else
-  const int mode = n > cus + cus / 4 ? 2 : 16;
+  const bool paired = n <= cus + cus / 2;
 #endif
-  if (mode == 2) gemm_jobs_kernel<2, false><<<n, kGjThreads, kGjLds<2>, s>>>(ga);
-  else if (mode == 5) gemm_jobs_kernel<5, false><<<n, kGjThreads, kGjLds<5>, s>>>(ga);
-  else gemm_jobs_kernel<2, true><<<n, 2 * kGjThreads, 2 * kGjLds<2>, s>>>(ga);
+  if (paired) gemm_jobs_kernel<true><<<n, 2 * kGjThreads, 2 * kGjLds, s>>>(ga);
+  else gemm_jobs_kernel<false><<<n, kGjThreads, kGjLds, s>>>(ga);
 }
 
 // returns 1 when the shapes do not qualify (the caller keeps its other kernels)

@@ -1,12 +1,12 @@
 #!/bin/bash
 # Developer tool (GPU box): per-launch durations of the ring GEMM inside a cfg4 / cfg3 step for every ring variant forced
-# (gemm_jobs.o rebuilt with -DGJ_DIAG_FORCE_SLOTS=<mode>; the library as built runs first).  usage: bash tools/kb6.sh [workloads]
+# (gemm_jobs.o rebuilt with -DGJ_DIAG_FORCE_MODE=<2|16>; the library as built runs first).  usage: bash tools/kb6.sh [workloads]
 R=$GRAFT_REPO_ROOT
 C=$(ls -d $R/prediction-*_amd/csrc)
 cd /tmp && export TMPDIR=/tmp
-for mode in default 5 2 16; do
+for mode in default 2 16; do
   if [ "$mode" != "default" ]; then
-    (cd $C && hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -fno-gpu-rdc -DGJ_DIAG_FORCE_SLOTS=$mode -c gemm_jobs.hip -o _build/gemm_jobs.o && make > /dev/null 2>&1) || exit 1
+    (cd $C && hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -fno-gpu-rdc -DGJ_DIAG_FORCE_MODE=$mode -c gemm_jobs.hip -o _build/gemm_jobs.o && make > /dev/null 2>&1) || exit 1
   fi
   for wl in ${@:-cfg4}; do
     OUT=$R/gpurun_out/kb6_${mode}_$wl
