@@ -233,8 +233,12 @@ template <typename T, int MT, bool WREG> static size_t conv_t_lds(int cin, int K
 }
 
 
-template <typename T, int BN, bool FWD>
-__global__ __launch_bounds__(kThreads, 2) void conv_direct_kernel(const T* __restrict__ x, const T* __restrict__ w,
+// NTHR = 512 (fp32): waves 4-7 are a second group on the same 128 x BN tile that multiplies the ODD k-steps of every weight chunk
+// (the first group the even ones); the two accumulator sets meet in the LDS output slab (first + second).  Two workgroups fit a
+// CU either way (the activation tile sets the LDS), so this is four waves per SIMD instead of two -- what the fp32 matrix pipe
+// needs to stay fed through LDS reads and barriers (gemm_jobs.h).
+template <typename T, int BN, bool FWD, int NTHR>
+__global__ __launch_bounds__(NTHR, NTHR == 512 ? 4 : 2) void conv_direct_kernel(const T* __restrict__ x, const T* __restrict__ w,
                                                                const typename AccOf<T>::type* __restrict__ bias, T* __restrict__ out,
                                                                typename AccOf<T>::type* __restrict__ partial, int B, int L, int cin,
                                                                int KK, int N, int pad, int SB, int tiles_t, int slot, int tiles_n) {
@@ -243,7 +247,9 @@ __global__ __launch_bounds__(kThreads, 2) void conv_direct_kernel(const T* __res
   using V = typename Vec16<T>::type;
   constexpr int VEC = Elem<T>::VEC, KSTEP = Mm::KSTEP, WCH = DCfg<T>::WCH, BT = kConvBT, MI = 2, NI = BN / 16;
   constexpr int WS = WCH + DCfg<T>::WPAD, CS = BN + 4;
-  constexpr int WV = BN * WCH / VEC / kThreads;   // weight vectors per thread and chunk
+  constexpr int WV = BN * WCH / VEC / NTHR;       // weight vectors per thread and chunk
+  constexpr int KSPLIT = NTHR / 256;              // groups of four waves sharing the reduction
+  static_assert(WV >= 1 && BN * WCH / VEC % NTHR == 0, "weight chunk / thread count");
   constexpr bool BF = sizeof(T) == 2;
   extern __shared__ __attribute__((aligned(16))) char arena[];
   const int tn = blockIdx.x % tiles_n, tm = blockIdx.x / tiles_n;
@@ -254,12 +260,12 @@ __global__ __launch_bounds__(kThreads, 2) void conv_direct_kernel(const T* __res
   T* ws1 = ws0 + BN * WS;
   const int KKp = (KK + KSTEP - 1) / KSTEP * KSTEP, nch = (KKp + WCH - 1) / WCH;
 
-  stage_x_tile<T>(x, xs, XS, xrows, SB, slot, b0, t0, B, L, cin, pad);
+  stage_x_tile<T, NTHR>(x, xs, XS, xrows, SB, slot, b0, t0, B, L, cin, pad);
   V wreg[WV];
   auto loadw = [&](int ch) {
 #pragma unroll
     for (int i = 0; i < WV; ++i) {
-      const int v = threadIdx.x + i * kThreads;
+      const int v = threadIdx.x + i * NTHR;
       const int n = v / (WCH / VEC), kc = (v % (WCH / VEC)) * VEC, kk = ch * WCH + kc;
       V val;
 #pragma unroll
@@ -271,7 +277,7 @@ __global__ __launch_bounds__(kThreads, 2) void conv_direct_kernel(const T* __res
   auto storew = [&](T* dst) {
 #pragma unroll
     for (int i = 0; i < WV; ++i) {
-      const int v = threadIdx.x + i * kThreads;
+      const int v = threadIdx.x + i * NTHR;
       const int n = v / (WCH / VEC), kc = (v % (WCH / VEC)) * VEC;
       lds_store_vec<T>(dst + n * WS + kc, wreg[i]);
     }
@@ -280,7 +286,7 @@ __global__ __launch_bounds__(kThreads, 2) void conv_direct_kernel(const T* __res
   storew(ws0);
   __syncthreads();
 
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, g = lane >> 4, r16 = lane & 15;
+  const int lane = threadIdx.x & 63, wave = (threadIdx.x >> 6) & 3, sub = threadIdx.x >> 8, g = lane >> 4, r16 = lane & 15;
   int xrow[MI];
 #pragma unroll
   for (int mi = 0; mi < MI; ++mi) xrow[mi] = tile_xrow(wave * 32 + mi * 16 + r16, L, SB, slot);
@@ -297,7 +303,8 @@ __global__ __launch_bounds__(kThreads, 2) void conv_direct_kernel(const T* __res
     if (more) loadw(ch + 1);
     const T* wt = (ch & 1) ? ws1 : ws0;
 #pragma unroll
-    for (int ks = 0; ks < WCH / KSTEP; ++ks) {
+    for (int k2 = 0; k2 < WCH / KSTEP / KSPLIT; ++k2) {
+      const int ks = k2 * KSPLIT + (KSPLIT > 1 ? sub : 0);
       const int kk0 = ch * WCH + ks * KSTEP;
       if (kk0 < KKp) {
         const int kl = BF ? 8 * g : g;                 // this lane's k offset inside the MFMA k-step
@@ -322,15 +329,22 @@ __global__ __launch_bounds__(kThreads, 2) void conv_direct_kernel(const T* __res
   // ---- epilogue: accumulators -> LDS slab -> coalesced row-major stores (+ BatchNorm partial sums)
   Acc* cs = reinterpret_cast<Acc*>(arena);
 #pragma unroll
-  for (int mi = 0; mi < MI; ++mi)
+  for (int q = 0; q < KSPLIT; ++q) {               // first group stores, the second adds
+    if (sub == q) {
 #pragma unroll
-    for (int ni = 0; ni < NI; ++ni)
+      for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
-      for (int r = 0; r < 4; ++r)
-        cs[(wave * 32 + mi * 16 + Mm::acc_row(lane, r)) * CS + ni * 16 + r16] = acc[mi][ni][r];
-  __syncthreads();
+        for (int ni = 0; ni < NI; ++ni)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            Acc* dst = &cs[(wave * 32 + mi * 16 + Mm::acc_row(lane, r)) * CS + ni * 16 + r16];
+            *dst = q == 0 ? acc[mi][ni][r] : *dst + acc[mi][ni][r];
+          }
+    }
+    __syncthreads();
+  }
   const bool multi = L < BT;
-  for (int gidx = threadIdx.x; gidx < BT * BN / 4; gidx += kThreads) {
+  for (int gidx = threadIdx.x; gidx < BT * BN / 4; gidx += NTHR) {
     const int r = gidx / (BN / 4), cq = (gidx % (BN / 4)) * 4;
     const int s = multi ? r / L : 0, tl = multi ? r - s * L : r;
     const bool rv = (multi ? r < SB * L : true) && (b0 + s < B) && (t0 + tl < L);
@@ -358,7 +372,7 @@ __global__ __launch_bounds__(kThreads, 2) void conv_direct_kernel(const T* __res
   }
   if (FWD) {
     __syncthreads();
-    constexpr int PARTS = kThreads / BN;
+    constexpr int PARTS = NTHR / BN;
     Acc* red = cs + BT * CS;
     const int colr = threadIdx.x % BN, part = threadIdx.x / BN;
     Acc s1 = 0, s2 = 0;
@@ -382,11 +396,12 @@ __global__ __launch_bounds__(kThreads, 2) void conv_direct_kernel(const T* __res
   }
 }
 
+template <typename T> constexpr int kDirectThreads = sizeof(T) == 4 ? 512 : 256;   // fp32: two groups of four waves (conv_direct_kernel)
 template <typename T, int BN> static size_t conv_direct_lds(int cin, int SB, int slot) {
   using Acc = typename AccOf<T>::type;
   const size_t xs = ((size_t)(SB * slot + kXExtra) * (cin + DCfg<T>::XPAD) + 7) & ~(size_t)7;
   const size_t op = (xs + 2 * (size_t)BN * (DCfg<T>::WCH + DCfg<T>::WPAD)) * sizeof(T);
-  const size_t ep = ((size_t)kConvBT * (BN + 4) + 2 * kThreads) * sizeof(Acc);
+  const size_t ep = ((size_t)kConvBT * (BN + 4) + 2 * kDirectThreads<T>) * sizeof(Acc);
   return ((op > ep ? op : ep) + 15) & ~(size_t)15;
 }
 
@@ -467,10 +482,10 @@ static int launch_direct(const void* x, const void* w, const void* bias, void* o
   if (lds > kMaxDirectLds) return 1;   // caller falls back to the generic GEMM view
   static size_t attr = 0;
   if (lds > attr) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_direct_kernel<T, BN, FWD>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kMaxDirectLds);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_direct_kernel<T, BN, FWD, kDirectThreads<T>>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kMaxDirectLds);
     attr = kMaxDirectLds;
   }
-  conv_direct_kernel<T, BN, FWD><<<t.tiles_m * tiles_n, kThreads, lds, s>>>((const T*)x, (const T*)w, (const Acc*)bias, (T*)out,
+  conv_direct_kernel<T, BN, FWD, kDirectThreads<T>><<<t.tiles_m * tiles_n, kDirectThreads<T>, lds, s>>>((const T*)x, (const T*)w, (const Acc*)bias, (T*)out,
                                                                         (Acc*)partial, B, L, cin, KK, N, pad, t.SB, t.tiles_t, t.slot, tiles_n);
   EMB_CHECK_LAUNCH();
   if (partial_rows) *partial_rows = t.tiles_m;
