@@ -512,8 +512,10 @@ int launch_conv_direct(int dtype, bool fwd, const void* x, const void* w, const 
 
 // ------------------------------------------------------------------------------------ weight gradient
 // slab[slice][o][n] += sum over the slice's row tiles of dy[r][o] * xview[r][n]  (n = tap*cin + ci);  column KK = sum dy
-template <typename T, int BMW>
-__global__ __launch_bounds__(kThreads, 2) void conv_wgrad_direct_kernel(const T* __restrict__ dy, const T* __restrict__ x,
+// NTHR = 512 (fp32): waves 4-7 multiply the odd k-steps of every row tile, waves 0-3 the even ones (conv_direct_kernel's reason:
+// four waves per SIMD); the second group's sums cross to the first through LDS after the last tile.
+template <typename T, int BMW, int NTHR>
+__global__ __launch_bounds__(NTHR, NTHR == 512 ? 4 : 2) void conv_wgrad_direct_kernel(const T* __restrict__ dy, const T* __restrict__ x,
                                                                      typename AccOf<T>::type* __restrict__ slab, int B, int L, int cin,
                                                                      int KK, int Cout, int pad, int SB, int tiles_t, int slot,
                                                                      int tiles_m, int n_tiles, int m_tiles, int S) {
@@ -531,7 +533,8 @@ __global__ __launch_bounds__(kThreads, 2) void conv_wgrad_direct_kernel(const T*
   T* xs = reinterpret_cast<T*>(arena);
   T* dys = xs + (((long)xrows * XS + 7) & ~7L);
   int* rowmap = reinterpret_cast<int*>(dys + BT * DS);
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, g = lane >> 4, r16 = lane & 15, q = r16 >> 2, p = r16 & 3;
+  constexpr int KSPLIT = NTHR / 256;
+  const int lane = threadIdx.x & 63, wave = (threadIdx.x >> 6) & 3, sub = threadIdx.x >> 8, g = lane >> 4, r16 = lane & 15, q = r16 >> 2, p = r16 & 3;
   if (threadIdx.x < BT) rowmap[threadIdx.x] = tile_xrow(threadIdx.x, L, SB, slot);
 
   // per n-block LDS offset of (tap, ci): the B operand element (n, row r) is xs[(rowmap[r] + tap(n)) * XS + ci(n)]
@@ -567,16 +570,17 @@ __global__ __launch_bounds__(kThreads, 2) void conv_wgrad_direct_kernel(const T*
   const int per = (tiles_m + S - 1) / S, tm_begin = slice * per, tm_end = min(tiles_m, tm_begin + per);
   CONV_T(1, 0);
   constexpr bool PF = sizeof(T) < 8;                       // register-staged prefetch (f64: direct staging)
-  constexpr int DV = BT * (BMW / VEC) / kThreads;          // dy-tile vectors per thread
+  constexpr int DV = BT * (BMW / VEC) / NTHR;              // dy-tile vectors per thread
+  static_assert(DV >= 1 && BT * (BMW / VEC) % NTHR == 0, "dy tile / thread count");
   const bool multi = L < BT;
   XPlan<T> xp;
   V xr[kXV], dr[DV];
   int d_glb[DV], d_pk[DV];
   if constexpr (PF) {
-    xplan_init<T>(xp, XS, xrows, SB, slot, L, cin, pad);
+    xplan_init<T, NTHR>(xp, XS, xrows, SB, slot, L, cin, pad);
 #pragma unroll
     for (int i = 0; i < DV; ++i) {
-      const int idx = threadIdx.x + i * kThreads;
+      const int idx = threadIdx.x + i * NTHR;
       const int r = idx / (BMW / VEC), cv = (idx % (BMW / VEC)) * VEC;
       const int sq = multi ? r / L : 0, tl = multi ? r - sq * L : r;
       d_glb[i] = (sq * L + tl) * Cout + o0 + cv;
@@ -605,15 +609,15 @@ __global__ __launch_bounds__(kThreads, 2) void conv_wgrad_direct_kernel(const T*
     CONV_T(1, 1 + (tm - tm_begin) * 4 + 0);
     if constexpr (PF) {
       if (!CONV_DBG(3)) xplan_commit<T>(xp, xr, xs);
-      if (xrows * (cin / VEC) > kXV * kThreads) stage_x_tile<T>(x, xs, XS, xrows, SB, slot, b0, t0, B, L, cin, pad, kXV * kThreads);
+      if (xrows * (cin / VEC) > kXV * NTHR) stage_x_tile<T, NTHR>(x, xs, XS, xrows, SB, slot, b0, t0, B, L, cin, pad, kXV * NTHR);
 #pragma unroll
       for (int i = 0; i < (CONV_DBG(3) ? 0 : DV); ++i) {
-        const int idx = threadIdx.x + i * kThreads;
+        const int idx = threadIdx.x + i * NTHR;
         *reinterpret_cast<V*>(dys + (idx / (BMW / VEC)) * DS + (idx % (BMW / VEC)) * VEC) = dr[i];   // DS * sizeof(T) % 16 == 0
       }
     } else {
-      stage_x_tile<T>(x, xs, XS, xrows, SB, slot, b0, t0, B, L, cin, pad);
-      for (int i = threadIdx.x; i < BT * (BMW / VEC); i += kThreads) {   // dy rows of this tile, zero where invalid
+      stage_x_tile<T, NTHR>(x, xs, XS, xrows, SB, slot, b0, t0, B, L, cin, pad);
+      for (int i = threadIdx.x; i < BT * (BMW / VEC); i += NTHR) {   // dy rows of this tile, zero where invalid
         const int r = i / (BMW / VEC), cv = (i % (BMW / VEC)) * VEC;
         const int sq = multi ? r / L : 0, tl = multi ? r - sq * L : r;
         const bool rv = (multi ? r < SB * L : true) && (b0 + sq < B) && (t0 + tl < L);
@@ -631,7 +635,8 @@ __global__ __launch_bounds__(kThreads, 2) void conv_wgrad_direct_kernel(const T*
     }
     CONV_T(1, 1 + (tm - tm_begin) * 4 + 2);
 #pragma unroll 4
-    for (int ks = 0; ks < (CONV_DBG(0) ? 0 : BT / KSTEP); ++ks) {
+    for (int k2 = 0; k2 < (CONV_DBG(0) ? 0 : BT / KSTEP / KSPLIT); ++k2) {
+      const int ks = k2 * KSPLIT + (KSPLIT > 1 ? sub : 0);
       typename Mm::Frag af[MIW], bf[NIW];
       if (BF) {
         typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
@@ -673,6 +678,33 @@ __global__ __launch_bounds__(kThreads, 2) void conv_wgrad_direct_kernel(const T*
     }
     CONV_T(1, 1 + (tm - tm_begin) * 4 + 3);
   }
+  if constexpr (KSPLIT > 1) {   // second group's sums -> first group: [wave][register][lane] floats, lane-linear
+    constexpr int NREG = MIW * NIW * 4 + MIW * 4;
+    Acc* xch = reinterpret_cast<Acc*>(arena);
+    __syncthreads();            // the last tile's operands are dead
+#pragma unroll
+    for (int pass = 0; pass < 2; ++pass) {
+      if (sub == 1 - pass) {
+#pragma unroll
+        for (int mi = 0; mi < MIW; ++mi) {
+#pragma unroll
+          for (int ni = 0; ni < NIW; ++ni)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+              Acc* e = &xch[(wave * NREG + (mi * NIW + ni) * 4 + r) * 64 + lane];
+              if (pass == 0) *e = acc[mi][ni][r]; else acc[mi][ni][r] += *e;
+            }
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            Acc* e = &xch[(wave * NREG + MIW * NIW * 4 + mi * 4 + r) * 64 + lane];
+            if (pass == 0) *e = bias_acc[mi][r]; else bias_acc[mi][r] += *e;
+          }
+        }
+      }
+      if (pass == 0) __syncthreads();
+    }
+    if (sub != 0) return;
+  }
   Acc* dst = slab + (long)slice * Cout * (KK + 1);
 #pragma unroll
   for (int mi = 0; mi < MIW; ++mi)
@@ -698,7 +730,10 @@ __global__ __launch_bounds__(kThreads, 2) void conv_wgrad_direct_kernel(const T*
 template <typename T, int BMW> static size_t wgrad_direct_lds(int cin, int SB, int slot) {
   constexpr int DS = BMW + (sizeof(T) == 2 ? 8 : 16);
   const size_t xs = ((size_t)(SB * slot + kXExtra) * (cin + DCfg<T>::XPAD) + 7) & ~(size_t)7;
-  return (((xs + (size_t)kConvBT * DS) * sizeof(T) + kConvBT * sizeof(int)) + 15) & ~(size_t)15;
+  const size_t op = (((xs + (size_t)kConvBT * DS) * sizeof(T) + kConvBT * sizeof(int)) + 15) & ~(size_t)15;
+  // two groups of waves (fp32): the exchange of the second group's sums, [4 waves][registers][64 lanes]
+  const size_t xch = kDirectThreads<T> > 256 ? (size_t)4 * ((BMW / 16) * (DCfg<T>::BNW / 64) * 4 + (BMW / 16) * 4) * 64 * sizeof(typename AccOf<T>::type) : 0;
+  return op > xch ? op : xch;
 }
 
 template <typename T> static int wgrad_slices_t(int B, int L, int pad, int KK, int Cout) {
@@ -734,11 +769,11 @@ static int launch_wgrad(const void* dy, const void* x, void* slab, int B, int L,
   if (lds > kMaxDirectLds) return 1;
   static size_t attr = 0;
   if (lds > attr) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wgrad_direct_kernel<T, BMW>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kMaxDirectLds);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wgrad_direct_kernel<T, BMW, kDirectThreads<T>>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kMaxDirectLds);
     attr = kMaxDirectLds;
   }
   const int n_tiles = cdiv(KK, DCfg<T>::BNW), m_tiles = cdiv(Cout, BMW);
-  conv_wgrad_direct_kernel<T, BMW><<<n_tiles * m_tiles * S, kThreads, lds, s>>>((const T*)dy, (const T*)x, (Acc*)slab, B, L, cin, KK, Cout,
+  conv_wgrad_direct_kernel<T, BMW, kDirectThreads<T>><<<n_tiles * m_tiles * S, kDirectThreads<T>, lds, s>>>((const T*)dy, (const T*)x, (Acc*)slab, B, L, cin, KK, Cout,
                                                                                pad, t.SB, t.tiles_t, t.slot, t.tiles_m, n_tiles, m_tiles, S);
   EMB_CHECK_LAUNCH();
   return EMB_OK;
