@@ -423,7 +423,7 @@ static int launch_conv_t_cfg(const void* x, const void* w, const void* bias, voi
   const size_t lds = conv_t_lds<T, MT, WREG>(cin, KK, xrows, WAVES);
   if (lds > kMaxDirectLds) return 1;
   int per_cu = (int)((160 * 1024) / lds);               // workgroups resident per CU: LDS, then ~2 waves per SIMD of registers
-  const int cap = WAVES == 4 ? 2 : 1;
+  const int cap = WAVES == 4 ? 2 : 1;                   // (eight-wave workgroups two per CU: measured slower, fp32 first blocks +14 %)
   per_cu = per_cu < 1 ? 1 : (per_cu > cap ? cap : per_cu);
   const int target = 256 * per_cu;
   const int tpb = cdiv(t.tiles_m * tiles_n, target) < 1 ? 1 : cdiv(t.tiles_m * tiles_n, target);
@@ -761,22 +761,30 @@ int conv_wgrad_slices(int B, int L, int cin, int pad, int KK, int Cout, int dtyp
   }
 }
 
-template <typename T, int BMW>
-static int launch_wgrad(const void* dy, const void* x, void* slab, int B, int L, int cin, int KK, int Cout, int pad, int S, hipStream_t s) {
+template <typename T, int BMW, int NTHR>
+static int launch_wgrad_n(const void* dy, const void* x, void* slab, int B, int L, int cin, int KK, int Cout, int pad, int S, hipStream_t s) {
   using Acc = typename AccOf<T>::type;
   const ConvTiling t = conv_tiling(B, L, pad);
   const size_t lds = wgrad_direct_lds<T, BMW>(cin, t.SB, t.slot);
   if (lds > kMaxDirectLds) return 1;
   static size_t attr = 0;
   if (lds > attr) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wgrad_direct_kernel<T, BMW, kDirectThreads<T>>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kMaxDirectLds);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wgrad_direct_kernel<T, BMW, NTHR>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kMaxDirectLds);
     attr = kMaxDirectLds;
   }
   const int n_tiles = cdiv(KK, DCfg<T>::BNW), m_tiles = cdiv(Cout, BMW);
-  conv_wgrad_direct_kernel<T, BMW, kDirectThreads<T>><<<n_tiles * m_tiles * S, kDirectThreads<T>, lds, s>>>((const T*)dy, (const T*)x, (Acc*)slab, B, L, cin, KK, Cout,
-                                                                               pad, t.SB, t.tiles_t, t.slot, t.tiles_m, n_tiles, m_tiles, S);
+  conv_wgrad_direct_kernel<T, BMW, NTHR><<<n_tiles * m_tiles * S, NTHR, lds, s>>>((const T*)dy, (const T*)x, (Acc*)slab, B, L, cin, KK, Cout, pad, t.SB,
+                                                                                 t.tiles_t, t.slot, t.tiles_m, n_tiles, m_tiles, S);
   EMB_CHECK_LAUNCH();
   return EMB_OK;
+}
+template <typename T, int BMW>
+static int launch_wgrad(const void* dy, const void* x, void* slab, int B, int L, int cin, int KK, int Cout, int pad, int S, hipStream_t s) {
+  // the second group of waves pays where the matrix work dominates the tile (>= 32 input channels); the first block's 4-channel
+  // tiles are staging-bound and ran 30 % slower with it
+  if constexpr (kDirectThreads<T> > 256)
+    if (cin >= 32) return launch_wgrad_n<T, BMW, kDirectThreads<T>>(dy, x, slab, B, L, cin, KK, Cout, pad, S, s);
+  return launch_wgrad_n<T, BMW, 256>(dy, x, slab, B, L, cin, KK, Cout, pad, S, s);
 }
 
 template <typename T> static int launch_wgrad_t(const void* dy, const void* x, void* slab, int B, int L, int cin, int KK, int Cout,
