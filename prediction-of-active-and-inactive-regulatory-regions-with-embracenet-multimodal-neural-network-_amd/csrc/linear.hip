@@ -26,6 +26,7 @@ template <typename T> struct LinCfg;
 template <> struct LinCfg<float> {
   using F = TileCfg<float, 64, 64, 32, 2, 2, 1, false, false>;
   using FS = TileCfg<float, 32, 32, 128, 1, 1, 4, false, false>;
+  using FS16 = TileCfg<float, 16, 32, 128, 1, 1, 4, false, false>;   // very few 32 x 32 tiles (B = 1024 rows into <= 64 units)
   using D = TileCfg<float, 64, 64, 32, 2, 2, 1, false, true>;
   using W = TileCfg<float, 64, 64, 32, 2, 2, 1, true, true>;
 };
@@ -196,6 +197,10 @@ static int linear_fwd_dispatch(const void* X, const void* W, const void* b, void
   const long tiles_L = (long)cdiv(B, 64) * cdiv(N, 64);
   if (tiles_L >= 192 || K < 256)
     return launch_linear_fwd<typename LinCfg<T>::F>(X, W, b, Y, mask, relu, dropout_p, layer_id, seed, step_val, step_dev, row0, B, K, N, s);
+  if constexpr (sizeof(T) == 4) {
+    if ((long)cdiv(B, 32) * cdiv(N, 32) <= 64)   // a first FFNN layer (562 -> 32 at B = 1024: 32 tiles of 32 x 32 ran 30 us)
+      return launch_linear_fwd<typename LinCfg<T>::FS16>(X, W, b, Y, mask, relu, dropout_p, layer_id, seed, step_val, step_dev, row0, B, K, N, s);
+  }
   return launch_linear_fwd<typename LinCfg<T>::FS>(X, W, b, Y, mask, relu, dropout_p, layer_id, seed, step_val, step_dev, row0, B, K, N, s);
 }
 

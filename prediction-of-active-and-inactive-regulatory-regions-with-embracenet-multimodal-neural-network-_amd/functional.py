@@ -3,6 +3,7 @@
 Everything here only enqueues work on torch's current HIP stream; nothing synchronises, so a whole
 train step built from these functions can be captured into a hipGraph (torch.cuda.CUDAGraph).
 """
+import itertools
 import torch
 
 from . import _lib
@@ -223,6 +224,10 @@ class _EmbraceFn(torch.autograd.Function):
                                              rng.seed, rng.step_val, ptr(rng.step_dev), rng.row0, ptr(E), ptr(code),
                                              B, d0, d1, c, DTYPE_CODE[T], stream()), "emb_embrace_fwd")
         ctx.save_for_backward(x0c, x1c, w0c, w1c, code)
+        # a hand-over of pre-masked gradients (_PREMASKED) must come from THIS forward: the code tensor carries a serial number
+        # the head copies into its hand-over and the backward checks (pointers alone repeat once the allocator recycles them)
+        _PREMASKED.clear()
+        ctx.code_serial = code._emb_serial = next(_CODE_SERIAL)
         ctx.T = T
         ctx.in_dtypes = (x0.dtype, x1.dtype, w0.dtype, b0.dtype, w1.dtype, b1.dtype)
         ctx.sinks = tuple(grad_sink(q, P) for q in (w0, b0, w1, b1))
@@ -254,8 +259,10 @@ class _EmbraceFn(torch.autograd.Function):
         # the producer of dE may have left the pre-masked gradients dD_m = dE * keep_m of THIS forward's code bytes (the fused
         # classifier head does: _HeadCEFn): then the backward is four plain GEMMs (csrc/gemm_jobs.h)
         pm = _PREMASKED.pop(dE.data_ptr(), None)
-        if pm is not None and not (pm[2] == code.data_ptr() and pm[0].shape == (B, c) and pm[0].dtype == T):
+        if pm is not None and not (pm[3] == ctx.code_serial and pm[2] == code.data_ptr() and pm[0].shape == (B, c) and pm[0].dtype == T):
             pm = None
+        if pm is not None:
+            pm = pm[:3]
         ok = bool(L_.emb_embrace_bwd_masked_supported(B, d0, d1, c, DTYPE_CODE[T])) and (B * c) % 8 == 0
         if pm is None and T != torch.float32:
             ok = False                 # bf16: a separate mask launch costs more than the fragment masks of emb_embrace_bwd
@@ -281,7 +288,8 @@ class _EmbraceFn(torch.autograd.Function):
 
 
 _AFTER_EMBRACE_BWD = None
-_PREMASKED = {}      # dE.data_ptr() -> (dD0, dD1, code.data_ptr()): left by the producer of dE for the fusion layer's backward
+_PREMASKED = {}      # dE.data_ptr() -> (dD0, dD1, code.data_ptr(), code serial): left by the producer of dE for the fusion layer's backward
+_CODE_SERIAL = itertools.count(1)
 
 
 def set_after_embrace_backward(fn):
@@ -737,7 +745,7 @@ class _HeadCEFn(torch.autograd.Function):
         check(L_.emb_head_ce_masked(ptr(Ec), ptr(Wc), ptr(bc), ptr(tgt), ptr(arm.class_counts), int(arm.global_counts), ptr(logits),
                                     ptr(dE), ptr(code) if masked else None, ptr(dD0), ptr(dD1), ptr(ws), ws.numel(), ptr(ta),
                                     ptr(tb), B, K, DTYPE_CODE[T], stream()), "emb_head_ce_masked")
-        ctx.premasked = (dD0, dD1, code.data_ptr()) if masked else None
+        ctx.premasked = (dD0, dD1, code.data_ptr(), getattr(code, "_emb_serial", None)) if masked else None
         if not train:                                            # evaluation: nothing else will come, finish now
             check(L_.emb_head_ce_finish(ptr(ws), None, None, ptr(arm.loss_out), ptr(arm.confusion), B, K, stream()), "emb_head_ce_finish")
         ctx.keep = (dE, ws, arm.loss_out, arm.confusion, B, K, E.dtype)

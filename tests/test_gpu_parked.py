@@ -191,3 +191,42 @@ def test_reset_drops_parked_descriptors_on_every_stream(ea):
     torch.cuda.synchronize()
     ref = (torch.relu(x @ w.detach().t() + b.detach()) > 0).float().t() @ x
     assert torch.allclose(w.grad, ref, rtol=1e-4, atol=1e-3)
+
+
+@pytest.mark.parametrize("T", [torch.float32, torch.bfloat16], ids=["f32", "bf16"])
+def test_stale_premasked_handover_is_rejected(ea, T):
+    """functional._PREMASKED hands the fused head's pre-masked gradients to the fusion layer's backward, keyed by dE's address.
+    Addresses repeat once the allocator recycles them, so the hand-over also carries the serial number of the forward whose code
+    bytes it was made from: an entry of ANOTHER forward that happens to sit under the same addresses (forced here: every lookup
+    hits a poisoned entry with matching pointer, shape and dtype) must be ignored -- gradients equal to the clean run's."""
+    F = ea.functional
+    B, d0, d1, c = 256, 16, 192, 128
+    g = torch.Generator(device="cpu").manual_seed(3)
+    mk = lambda *s: (torch.rand(*s, generator=g) - 0.5).to(DEV)
+    x0, x1, w0, w1 = mk(B, d0), mk(B, d1), mk(c, d0), mk(c, d1) * 0.2
+    b0, b1 = torch.zeros(c, device=DEV), torch.zeros(c, device=DEV)
+    cdf0, _ = F.select_prep(torch.tensor([[0.4, 0.6]], device=DEV), None, B)
+    dE = mk(B, c).to(T)
+
+    class Poisoned(dict):
+        def pop(self, key, default=None):
+            code_ptr = self.code_ptr
+            junk = torch.full((B, c), 7.0, dtype=T, device=DEV)
+            return (junk, junk.clone(), code_ptr, -1)          # right pointers, right shape and dtype, wrong forward
+
+    def run(poison):
+        leaves = [t.clone().requires_grad_() for t in (x0, x1, w0, w1)]
+        E, code = F.embrace(leaves[0], leaves[1], leaves[2], b0, leaves[3], b1, cdf0, rng=F.RngState(seed=9), compute_dtype=T)
+        saved = F._PREMASKED
+        if poison:
+            F._PREMASKED = Poisoned()
+            F._PREMASKED.code_ptr = code.data_ptr()
+        try:
+            E.backward(dE.to(E.dtype))
+        finally:
+            F._PREMASKED = saved
+        torch.cuda.synchronize()
+        return [t.grad.clone() for t in leaves]
+
+    for a, b in zip(run(False), run(True)):
+        assert torch.equal(a, b)
