@@ -658,7 +658,7 @@ def main():
     def reduce_grads():
         if exch:
             flat.finish()                                 # waits for the first bucket, reduces the second (+ the shards' counts)
-            F.cast(flat.extra[2:4], torch.float32, out=flat.extra[0:2])
+            F.park_copy(flat.extra[2:4], flat.extra[0:2])   # done by the optimizer launch that follows
             return
         flat.extra.copy_(local_counts)                    # next batch's labels (synthetic: the same batch)
         flat.finish()

@@ -327,6 +327,12 @@ int emb_reduce_flush(emb_stream_t stream);
 /* Parked launch descriptors (queued reductions, rider, first-block finish / totals jobs) of `stream`, or of every stream when
  * all_streams != 0.  0 after a completed step. */
 int emb_parked_count(emb_stream_t stream, int all_streams);
+/* Parks a copy of n (1 .. 64) floats src -> dst on `stream`: the next emb_*_step_multi launch of the stream performs it (its first
+ * workgroup; the launch reads none of these floats otherwise), emb_copy_flush runs it as a launch of its own if none did.  One slot
+ * per stream (parking a second copy first runs the parked one).  Data-parallel steps use it for the 8 bytes of all-reduced class
+ * counts the next step's emb_head_ce reads (global_counts == 2). */
+int emb_copy_park(emb_stream_t stream, const float* src, float* dst, int n);
+int emb_copy_flush(emb_stream_t stream);
 /* Drops everything parked on every stream WITHOUT launching it and returns every defer switch to off: the recovery call after an
  * exception between a deferring call and its flush (the parked descriptors point at tensors that may be gone).  Returns the
  * number of descriptors dropped.  Touches no device memory. */

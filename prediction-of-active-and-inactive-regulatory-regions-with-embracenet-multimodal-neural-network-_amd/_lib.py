@@ -73,6 +73,8 @@ SIGNATURES = {
     "emb_mt19937_shuffle": [_vp, _vp, _vp, _i64],
     "emb_reduce_defer": [_vp, _i],
     "emb_reduce_flush": [_vp],
+    "emb_copy_park": [_vp, _vp, _vp, _i],
+    "emb_copy_flush": [_vp],
     "emb_parked_count": [_vp, _i],
     "emb_reset": [],
     "emb_reset_stream": [_vp],

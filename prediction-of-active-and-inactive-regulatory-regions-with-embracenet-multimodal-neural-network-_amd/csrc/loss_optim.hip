@@ -334,6 +334,7 @@ template <typename P> struct MultiArgs {
   FirstFinArgs ff;
   int nff;
   signed char ff_t[4];
+  SmallCopy copy;               // a parked copy of a few floats (reduce.h): workgroup 0 does it
 };
 static_assert(sizeof(MultiArgs<float>) + 128 <= 4096, "kernel argument block");
 enum { OPT_ADAM = 0, OPT_RMSPROP = 1, OPT_NADAM = 2 };
@@ -499,6 +500,7 @@ __global__ __launch_bounds__(256) void multi_opt_kernel(const MultiArgs<P> args,
     for (int i = threadIdx.x; i < (int)(sizeof(MultiArgs<P>) / 4); i += 256) dst[i] = src[i];
   }
   __syncthreads();
+  if (blockIdx.x == 0 && (int)threadIdx.x < a.copy.n) a.copy.dst[threadIdx.x] = a.copy.src[threadIdx.x];
   const int bid = (int)blockIdx.x - a.nff;
   const int plain_end = a.blk_end[a.count - 1];
   const int slab_end = a.nsrc ? a.slab[a.nsrc - 1].blk_end : plain_end;
@@ -783,6 +785,8 @@ static int multi_launch(void* const* params, const void* const* grads, void* con
       for (int q = 0; q < 4; ++q) a.ff_t[q] = (signed char)fft[q];
     }
     if (blocks == 0 && a.nstats == 0 && a.nff == 0) continue;
+    a.copy = SmallCopy{};
+    if (off + cnt >= ntensors) (void)small_copy_take(s, &a.copy);   // (last chunk of the call: after every gradient was consumed)
     multi_opt_kernel<P, OPT><<<(int)blocks + a.nstats + a.nff, 256, 0, s>>>(a, h);
     EMB_CHECK_LAUNCH();
   }

@@ -53,4 +53,15 @@ __host__ __device__ inline long reduce_slab_index(int kind, const int* iv, int w
   return which < 4 ? off + i : off + (long)iv[1 + l] * iv[5 + l] + i;
 }
 
+// a few floats copied by the next optimizer launch of the stream (emb_copy_park; loss_optim.hip takes it, emb_copy_flush runs what
+// nobody took).  Data-parallel steps move the all-reduced class counts of the exchange block into the slot the next step's
+// classifier head reads -- 8 bytes that cost a 4.6 us launch as a kernel of their own.
+struct SmallCopy {              // (plain aggregate: it travels inside a kernel argument block; SmallCopy{} is the empty one)
+  const float* src;
+  float* dst;
+  int n;
+};
+bool small_copy_take(hipStream_t s, SmallCopy* out);
+int small_copy_flush(hipStream_t s);
+
 }  // namespace emb

@@ -137,8 +137,11 @@ struct Lot {
   GramJobsArgs jobs{};
   bool jobs_valid = false;
   Rider rider{};
-  bool idle() const { return f32.empty() && f64.empty() && !fin_valid && !jobs_valid && rider.kind == RIDER_NONE; }
-  int parked() const { return (int)f32.size() + (int)f64.size() + (fin_valid ? 1 : 0) + (jobs_valid ? 1 : 0) + (rider.kind != RIDER_NONE ? 1 : 0); }
+  SmallCopy copy{};            // a few floats the next optimizer launch copies (emb_copy_park)
+  bool idle() const { return f32.empty() && f64.empty() && !fin_valid && !jobs_valid && rider.kind == RIDER_NONE && copy.n == 0; }
+  int parked() const {
+    return (int)f32.size() + (int)f64.size() + (fin_valid ? 1 : 0) + (jobs_valid ? 1 : 0) + (rider.kind != RIDER_NONE ? 1 : 0) + (copy.n ? 1 : 0);
+  }
 };
 static std::recursive_mutex& lot_mutex() {
   static std::recursive_mutex m;
@@ -231,6 +234,24 @@ int first_fin_submit(const FirstFinArgs& f, hipStream_t s) {
   if (rc != EMB_OK) return rc;
   lot.fin = f;
   lot.fin_valid = true;
+  return EMB_OK;
+}
+// ---- a parked copy of a few floats (emb_copy_park): taken over by the next optimizer launch of the stream, else run at the flush
+__global__ void small_copy_kernel(SmallCopy c) {
+  if ((int)threadIdx.x < c.n) c.dst[threadIdx.x] = c.src[threadIdx.x];
+}
+bool small_copy_take(hipStream_t s, SmallCopy* out) {
+  EMB_LOT(lot, s);
+  if (lot.copy.n == 0) return false;
+  *out = lot.copy;
+  lot.copy = SmallCopy{};
+  return true;
+}
+int small_copy_flush(hipStream_t s) {
+  SmallCopy c;
+  if (!small_copy_take(s, &c)) return EMB_OK;
+  small_copy_kernel<<<1, 64, 0, s>>>(c);
+  EMB_CHECK_LAUNCH();
   return EMB_OK;
 }
 bool first_fin_peek(hipStream_t s, FirstFinArgs* out) {
@@ -338,6 +359,17 @@ extern "C" int emb_reduce_flush(emb_stream_t stream) {
   lot.f64.clear();
   return rc;
 }
+
+extern "C" int emb_copy_park(emb_stream_t stream, const float* src, float* dst, int n) {
+  EMB_CHECK_ARG(src && dst && n >= 1 && n <= 64, "emb_copy_park: 1 .. 64 floats");
+  hipStream_t s = (hipStream_t)stream;
+  const int rc = emb::small_copy_flush(s);   // (one slot per stream)
+  if (rc != EMB_OK) return rc;
+  EMB_LOT(lot, s);
+  lot.copy = emb::SmallCopy{src, dst, n};
+  return EMB_OK;
+}
+extern "C" int emb_copy_flush(emb_stream_t stream) { return emb::small_copy_flush((hipStream_t)stream); }
 
 extern "C" int emb_parked_count(emb_stream_t stream, int all_streams) {
   std::lock_guard<std::recursive_mutex> g(emb::lot_mutex());

@@ -807,6 +807,18 @@ def reduce_flush():
     check(_lib.lib().emb_reduce_flush(stream()), "emb_reduce_flush")
 
 
+def park_copy(src, dst):
+    """dst[:] = src (1 .. 64 fp32 values) by the NEXT fused optimizer launch of the stream instead of a launch of its own
+    (emb_copy_park); `flush_copy()` runs it if no optimizer launch follows."""
+    if src.dtype != torch.float32 or dst.dtype != torch.float32 or src.numel() != dst.numel() or not (src.is_contiguous() and dst.is_contiguous()):
+        raise ValueError("park_copy: contiguous fp32 tensors of equal size")
+    check(_lib.lib().emb_copy_park(stream(), ptr(src), ptr(dst), src.numel()), "emb_copy_park")
+
+
+def flush_copy():
+    check(_lib.lib().emb_copy_flush(stream()), "emb_copy_flush")
+
+
 def parked_count(all_streams=False):
     """Launch descriptors the library holds for the current stream (or all streams): queued slab reductions, a parked rider, the
     first conv block's parked finish / totals jobs.  0 after a completed step."""

@@ -230,3 +230,34 @@ def test_stale_premasked_handover_is_rejected(ea, T):
 
     for a, b in zip(run(False), run(True)):
         assert torch.equal(a, b)
+
+
+def test_parked_copy_rides_in_the_optimizer_launch_or_runs_at_the_flush(ea):
+    """emb_copy_park: a few floats copied by the next fused optimizer launch of the stream (the data-parallel step's 8 bytes of
+    all-reduced class counts); emb_copy_flush runs it when no optimizer launch took it; emb_reset drops it unlaunched."""
+    from embracenet_amd import optim
+    F = ea.functional
+    src = torch.tensor([3.0, 5.0], device=DEV)
+    dst = torch.zeros(2, device=DEV)
+    w = torch.nn.Parameter(torch.ones(1000, device=DEV))
+    opt = optim.Adam([w], lr=1e-2)
+    w.grad = torch.full_like(w, 0.5)
+    F.park_copy(src, dst)
+    assert F.parked_count() == 1
+    torch.cuda.synchronize()
+    assert dst.tolist() == [0.0, 0.0]                      # nothing has run yet
+    opt.step()
+    torch.cuda.synchronize()
+    assert dst.tolist() == [3.0, 5.0] and F.parked_count() == 0
+    assert float(w.detach().max()) < 1.0                   # the update itself happened
+    src.mul_(2)
+    F.park_copy(src, dst)
+    F.flush_copy()
+    torch.cuda.synchronize()
+    assert dst.tolist() == [6.0, 10.0] and F.parked_count() == 0
+    src.mul_(2)
+    F.park_copy(src, dst)
+    assert F.reset() == 1
+    opt.step()
+    torch.cuda.synchronize()
+    assert dst.tolist() == [6.0, 10.0]                     # dropped, not launched
