@@ -201,7 +201,7 @@ def kernel_roofline(ea, wl, device):
                                         rng.step_val, None, 0, ptr(E), ptr(code), B, d0, d1, c, code_of, st()), "fwd")
 
     # the backward as the step runs it: on the pre-masked gradients the classifier head leaves (emb_head_ce_masked) when the
-    # persistent ring GEMM takes the shape (csrc/gemm_jobs.h), else from dE and the code bytes (emb_embrace_bwd)
+    # fp32 tile GEMM takes the shape (csrc/gemm_jobs.h), else from dE and the code bytes (emb_embrace_bwd)
     masked = bool(L.emb_embrace_bwd_masked_supported(B, d0, d1, c, code_of))
     dD0, dD1 = torch.empty_like(dE), torch.empty_like(dE)
 
@@ -481,13 +481,13 @@ def step_accounting(wl, dims, ms_per_step, stats_csv, traffic_csv=None):
             })
     else:
         # fp32 / fp64: block 1 and the stored-activation blocks run the same kernel families; all convolution launches of the
-        # step are ONE class (forward + input gradient of blocks >= 2 + weight gradient of every block), the ring GEMM launches
-        # (csrc/gemm_jobs.h) carry the fusion layer's backward as well
+        # step are ONE class (forward + input gradient of blocks >= 2 + weight gradient of every block), the tile GEMM launches
+        # of csrc/gemm_jobs.h carry the fusion layer's backward and the backward of large Linear layers as well
         conv_fl = 3.0 * sum(cv["flops"] for cv in convs) - c0["flops"]
         conv_by = sum(3 * (cv["x"] + cv["y"]) for cv in convs)
         table["convolutions (all blocks: fwd, dgrad, wgrad)"] = (["conv_t_kernel<", "conv_direct_kernel<", "conv_wgrad_direct_kernel<", "conv_gemm_kernel",
                                                                   "conv_wgrad_kernel<", "first_kernel<"], conv_fl, conv_by)
-        table["ring GEMM (conv blocks with >= 128 channels + fusion backward)"] = (["gemm_jobs_kernel"], 0.0, 0)   # priced below
+        table["fp32 tile GEMM (conv blocks with >= 128 channels, fusion backward, large Linear backward)"] = (["gemm_jobs_kernel"], 0.0, 0)   # priced below
     table.update({
         "embrace_fwd": (["embrace_fwd"], *emb_f),
         "embrace_bwd": (["embrace_bwd"], *emb_b),
@@ -509,19 +509,28 @@ def step_accounting(wl, dims, ms_per_step, stats_csv, traffic_csv=None):
         once = [v[0] for n, v in rows.items() if "multi_opt_kernel" in n or "head_ce_kernel" in n or "weighted_ce" in n]
         steps = max(1.0, min(once)) if once else 1.0
     if rows and not bf:
-        # the ring GEMM launches: the fusion backward (its class is then empty) plus the conv jobs they took over
+        # the tile GEMM launches: the fusion backward (its class is then empty), the conv jobs they took over and the backward of
+        # Linear layers with B * in * out >= 2^27 (csrc/linear.hip)
         ring = [n for n in rows if "gemm_jobs_kernel" in n]
         if ring:
             ring_conv = sum(cv["flops"] * (2 if (cv["cin"] % 32 == 0 and cv["cout"] >= 128) else 0) for cv in rest)      # forward + weight gradient
             ring_conv += sum(cv["flops"] for cv in rest if cv["cout"] % 32 == 0 and cv["cin"] >= 128)                    # input gradient
-            name = "ring GEMM (conv blocks with >= 128 channels + fusion backward)"
-            table[name] = (["gemm_jobs_kernel"], ring_conv + emb_b[0], emb_b[1] + sum(2 * (cv["x"] + cv["y"]) for cv in rest if cv["cout"] >= 128))
+            big_lin = [(a, b_) for a, b_ in list(zip(ffw[:-1], ffw[1:])) + list(zip(pw[:-1], pw[1:]))
+                       if B * a * b_ >= (1 << 27) and a % 4 == 0 and b_ % 4 == 0]
+            lin_bwd = sum(4.0 * B * a * b_ for a, b_ in big_lin)
+            name = "fp32 tile GEMM (conv blocks with >= 128 channels, fusion backward, large Linear backward)"
+            table[name] = (["gemm_jobs_kernel"], ring_conv + emb_b[0] + lin_bwd,
+                           emb_b[1] + sum(2 * (cv["x"] + cv["y"]) for cv in rest if cv["cout"] >= 128) + sum(s * (2 * B * (a + b_) + 2 * a * b_) for a, b_ in big_lin))
             cname = "convolutions (all blocks: fwd, dgrad, wgrad)"
             f_, fl, by = table[cname]
             table[cname] = (f_, fl - ring_conv, by)
+            lname = "mlp / linear layers (epigenomic stack, hidden post layers)"
+            if lname in table and lin_bwd:
+                f_, fl, by = table[lname]
+                table[lname] = (f_ + ["linear_premask_kernel"], fl - lin_bwd, by)
             table.pop("embrace_bwd", None) if not any("embrace_bwd" in n for n in rows) else None
         else:
-            table.pop("ring GEMM (conv blocks with >= 128 channels + fusion backward)", None)
+            table.pop("fp32 tile GEMM (conv blocks with >= 128 channels, fusion backward, large Linear backward)", None)
     if rows:   # classes whose kernels did not run in this step
         table = {cls: v for cls, v in table.items() if any(f in n for f in v[0] for n in rows)}
     hbm = {}    # kernel name -> HBM bytes per launch from the committed PMC passes of this command (tools/run_pmc_hbm.sh)

@@ -1,5 +1,5 @@
 #!/bin/bash
-# Developer tool (GPU box): per-launch durations of the ring GEMM inside a cfg4 / cfg3 step for every ring variant forced
+# Developer tool (GPU box): per-launch durations of the fp32 tile GEMM (gemm_jobs.h) inside a cfg4 / cfg3 step for every variant forced
 # (gemm_jobs.o rebuilt with -DGJ_DIAG_FORCE_MODE=<2|16>; the library as built runs first).  usage: bash tools/kb6.sh [workloads]
 R=$GRAFT_REPO_ROOT
 C=$(ls -d $R/prediction-*_amd/csrc)

@@ -15,7 +15,7 @@ import csv, glob, json, os, sys
 from collections import defaultdict
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-GROUPS = {"embrace_fwd_kernel": ("embrace_fwd",), "embrace_bwd_kernel": ("embrace_bwd", "gemm_jobs")}   # (fp32: the ring GEMM is the backward)
+GROUPS = {"embrace_fwd_kernel": ("embrace_fwd",), "embrace_bwd_kernel": ("embrace_bwd", "gemm_jobs")}   # (fp32: the tile GEMM of gemm_jobs.h is the backward)
 
 
 def mean_counter(directory, counter):

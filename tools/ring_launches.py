@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Developer tool: the ring GEMM launches of one step, in launch order, from a rocprofv3 kernel trace of `bench.py --no-extras`
+"""Developer tool: the launches of the fp32 tile GEMM (gemm_jobs_kernel) of one step, in launch order, from a rocprofv3 kernel trace of `bench.py --no-extras`
 (average duration of each over the last ten steps, with its grid size).
 usage: python tools/ring_launches.py <dir with *_kernel_trace.csv> [marker substring of the FIRST kernel of a step]"""
 import csv, glob, os, sys
@@ -19,4 +19,4 @@ for i in range(n):
     t = sum(s[i][2] for s in steps) / len(steps)
     tot += t
     print(f"{i}: {steps[0][i][0]:48s} tiles {steps[0][i][1]:5d}  {t:8.2f} us")
-print(f"ring launches per step: {n}, {tot:.1f} us")
+print(f"tile GEMM launches per step: {n}, {tot:.1f} us")
