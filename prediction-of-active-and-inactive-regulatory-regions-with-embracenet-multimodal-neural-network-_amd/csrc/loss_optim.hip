@@ -490,14 +490,19 @@ __device__ __forceinline__ bool slab_target(const SlabSrc& j, long q, int* which
   return false;
 }
 
-template <typename P, int OPT>
-__global__ __launch_bounds__(256) void multi_opt_kernel(const MultiArgs<P> args, const Hyper h) {
+// NT threads per workgroup: 256, or 1024 when the first conv block's finish rides along -- its per-channel workgroups are the
+// launch's critical path and run the 1024-thread body of the standalone kernel (first_gram.h: 8.9 us against ~19 us with 256
+// threads; the same summation order as the standalone finish).  Every other role is indifferent to NT: a workgroup still owns
+// kChunk elements of a plain tensor / (NT / lanes) * vec slab elements, slices meet in lane order, the statistics sums keep
+// their 32 x 8 shape.
+template <typename P, int OPT, int NT>
+__global__ __launch_bounds__(NT) void multi_opt_kernel(const MultiArgs<P> args, const Hyper h) {
   __shared__ MultiArgs<P> a;
-  __shared__ P red[4][256];          // lane partial sums of slab-sourced gradients
+  __shared__ P red[4][NT];           // lane partial sums of slab-sourced gradients
   {
     const unsigned* src = reinterpret_cast<const unsigned*>(&args);
     unsigned* dst = reinterpret_cast<unsigned*>(&a);
-    for (int i = threadIdx.x; i < (int)(sizeof(MultiArgs<P>) / 4); i += 256) dst[i] = src[i];
+    for (int i = threadIdx.x; i < (int)(sizeof(MultiArgs<P>) / 4); i += NT) dst[i] = src[i];
   }
   __syncthreads();
   if (blockIdx.x == 0 && (int)threadIdx.x < a.copy.n) a.copy.dst[threadIdx.x] = a.copy.src[threadIdx.x];
@@ -510,8 +515,10 @@ __global__ __launch_bounds__(256) void multi_opt_kernel(const MultiArgs<P> args,
     const P* in = (const P*)sj.in;
     const int q = threadIdx.x & 7, sl = threadIdx.x >> 3;       // per == 8 values per slice (head.hip)
     P acc = 0;
-    for (int s = sl; s < sj.S; s += 32) acc += in[(long)s * sj.per + q];
-    red[0][threadIdx.x] = acc;
+    if (threadIdx.x < 256) {                                    // (32 slice groups x 8 values whatever NT: one summation order)
+      for (int s = sl; s < sj.S; s += 32) acc += in[(long)s * sj.per + q];
+      red[0][threadIdx.x] = acc;
+    }
     __syncthreads();
     if (threadIdx.x < 8) {
       P sum = 0;
@@ -542,7 +549,7 @@ __global__ __launch_bounds__(256) void multi_opt_kernel(const MultiArgs<P> args,
 
   if constexpr (sizeof(P) == 4) {
     if (bid < 0) {            // finish of the first conv block's backward for channel blockIdx.x, parameters updated on the spot
-      __shared__ __attribute__((aligned(16))) float fin_lds[first_finish_lds_floats<256>()];
+      __shared__ __attribute__((aligned(16))) float fin_lds[first_finish_lds_floats<NT>()];
       struct Sink {
         const MultiArgs<P>& a;
         const OptConst<P>& kc;
@@ -558,7 +565,7 @@ __global__ __launch_bounds__(256) void multi_opt_kernel(const MultiArgs<P> args,
         }
         __device__ __forceinline__ void dw(long idx, float v) const { one(0, idx, v, a.ff.dW); }
       };
-      first_finish_body<256>(a.ff, (int)blockIdx.x, fin_lds, Sink{a, kc, (int)blockIdx.x});
+      first_finish_body<NT>(a.ff, (int)blockIdx.x, fin_lds, Sink{a, kc, (int)blockIdx.x});
       return;
     }
   }
@@ -568,16 +575,16 @@ __global__ __launch_bounds__(256) void multi_opt_kernel(const MultiArgs<P> args,
     const long base = (long)(bid - (t == 0 ? 0 : a.blk_end[t - 1])) * kChunk;
     const P* g = a.g[t];
     const int n = a.n[t];
-    OptElem<P> el[kChunk / 256];
-    P gr[kChunk / 256];
+    OptElem<P> el[kChunk / NT];
+    P gr[kChunk / NT];
 #pragma unroll
-    for (int u = 0; u < kChunk / 256; ++u) {               // all loads first (see opt_load)
-      const long i = base + u * 256 + threadIdx.x;
+    for (int u = 0; u < kChunk / NT; ++u) {                // all loads first (see opt_load)
+      const long i = base + u * NT + threadIdx.x;
       if (i < n) { el[u] = opt_load<P, OPT>(a, t, i); gr[u] = g[i]; }
     }
 #pragma unroll
-    for (int u = 0; u < kChunk / 256; ++u) {
-      const long i = base + u * 256 + threadIdx.x;
+    for (int u = 0; u < kChunk / NT; ++u) {
+      const long i = base + u * NT + threadIdx.x;
       if (i < n) opt_apply<P, OPT>(a, kc, t, i, gr[u], el[u]);
     }
     return;
@@ -587,7 +594,7 @@ __global__ __launch_bounds__(256) void multi_opt_kernel(const MultiArgs<P> args,
   while (k < a.nsrc - 1 && bid >= a.slab[k].blk_end) ++k;
   const SlabSrc& sj = a.slab[k];
   const int jb = bid - (k == 0 ? plain_end : a.slab[k - 1].blk_end);
-  const int lanes = sj.lanes, qpb = 256 / lanes, qi = threadIdx.x % qpb, sl = threadIdx.x / qpb;
+  const int lanes = sj.lanes, qpb = NT / lanes, qi = threadIdx.x % qpb, sl = threadIdx.x / qpb;
   const long per = sj.per;
   const P* in = (const P*)sj.in;
   P acc[4] = {0, 0, 0, 0};
@@ -764,8 +771,20 @@ static int multi_launch(void* const* params, const void* const* grads, void* con
     }
     a.count = cnt;
     a.nsrc = nsrc;
+    // threads per workgroup (multi_opt_kernel): 1024 when a first-block finish rides along AND the rest of the launch is small
+    // enough for the finish to be its critical path (cfg2: ~1100 workgroups of 256; with cfg5's 2.9 M docking weights the
+    // 1024-thread launch was 29 us slower)
+    int nt = 256;
+    if (have_ff && sizeof(P) == 4) {
+      long b256 = blocks;
+      for (int k = 0; k < nsrc; ++k) {
+        const long epb = (long)(256 / a.slab[k].lanes) * a.slab[k].vec;
+        b256 += (a.slab[k].per + epb - 1) / epb;
+      }
+      if (b256 <= 2048) nt = 1024;
+    }
     for (int k = 0; k < nsrc; ++k) {
-      const long epb = (long)(256 / a.slab[k].lanes) * a.slab[k].vec;
+      const long epb = (long)(nt / a.slab[k].lanes) * a.slab[k].vec;
       blocks += (a.slab[k].per + epb - 1) / epb;
       a.slab[k].blk_end = (int)blocks;
     }
@@ -787,7 +806,8 @@ static int multi_launch(void* const* params, const void* const* grads, void* con
     if (blocks == 0 && a.nstats == 0 && a.nff == 0) continue;
     a.copy = SmallCopy{};
     if (off + cnt >= ntensors) (void)small_copy_take(s, &a.copy);   // (last chunk of the call: after every gradient was consumed)
-    multi_opt_kernel<P, OPT><<<(int)blocks + a.nstats + a.nff, 256, 0, s>>>(a, h);
+    if (nt == 1024) multi_opt_kernel<P, OPT, 1024><<<(int)blocks + a.nstats + a.nff, 1024, 0, s>>>(a, h);
+    else multi_opt_kernel<P, OPT, 256><<<(int)blocks + a.nstats + a.nff, 256, 0, s>>>(a, h);
     EMB_CHECK_LAUNCH();
   }
   return EMB_OK;
