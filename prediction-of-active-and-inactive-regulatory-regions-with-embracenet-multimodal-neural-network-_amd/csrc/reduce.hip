@@ -65,20 +65,22 @@ struct FinStoreR {
   }
   __device__ __forceinline__ void dw(long idx, float v) const { a.dW[idx] = v; }
 };
-template <typename P> __global__ __launch_bounds__(256) void multi_reduce_kernel(const ReduceTable tab, const FirstFinArgs fin, const int nfin) {
+// NT threads per workgroup: 256, or 1024 when the finish rides in a small launch (its workgroups are the critical path and then run
+// the 1024-thread body of the standalone kernel; multi_opt_kernel, loss_optim.hip, does the same).
+template <typename P, int NT> __global__ __launch_bounds__(NT) void multi_reduce_kernel(const ReduceTable tab, const FirstFinArgs fin, const int nfin) {
   if constexpr (sizeof(P) == 4) {
     if ((int)blockIdx.x < nfin) {
-      __shared__ __attribute__((aligned(16))) float fin_lds[first_finish_lds_floats<256>()];
-      first_finish_body<256>(fin, (int)blockIdx.x, fin_lds, FinStoreR{fin, (int)blockIdx.x});
+      __shared__ __attribute__((aligned(16))) float fin_lds[first_finish_lds_floats<NT>()];
+      first_finish_body<NT>(fin, (int)blockIdx.x, fin_lds, FinStoreR{fin, (int)blockIdx.x});
       return;
     }
   }
   __shared__ ReduceTable t;
-  __shared__ P red[4][256];
+  __shared__ P red[4][NT];
   {
     const unsigned* src = reinterpret_cast<const unsigned*>(&tab);
     unsigned* dst = reinterpret_cast<unsigned*>(&t);
-    for (int i = threadIdx.x; i < (int)(sizeof(ReduceTable) / 4); i += 256) dst[i] = src[i];
+    for (int i = threadIdx.x; i < (int)(sizeof(ReduceTable) / 4); i += NT) dst[i] = src[i];
   }
   __syncthreads();
   int ji = 0;
@@ -86,9 +88,33 @@ template <typename P> __global__ __launch_bounds__(256) void multi_reduce_kernel
   while (ji < t.n - 1 && blk >= t.d[ji].blk_end) ++ji;
   const DevJob& d = t.d[ji];
   const int bid = blk - (ji == 0 ? 0 : t.d[ji - 1].blk_end);
-  const int lanes = d.lanes, qpb = 256 / lanes, qi = threadIdx.x % qpb, sl = threadIdx.x / qpb;
+  const int lanes = d.lanes, qpb = NT / lanes, qi = threadIdx.x % qpb, sl = threadIdx.x / qpb;
   const long per = d.j.per;
   const P* in = (const P*)d.j.in;
+  if (d.vec == 4 && lanes == 1) {
+    // large row-major slabs (the docking weight gradients): every thread sums all slices of ITS four elements (independent 16-byte
+    // loads, slice order) and stores them as one vector when they are four weights of one row -- no exchange through LDS, no
+    // 4-byte stores at a 16-byte stride
+    typedef P P4 __attribute__((ext_vector_type(4)));
+    const long q = ((long)bid * qpb + qi) * 4;
+    if (q >= per) return;
+    P4 a = {0, 0, 0, 0};
+#pragma unroll 8
+    for (int s = 0; s < d.j.S; ++s) a += *reinterpret_cast<const P4*>(in + (long)s * per + q);
+    if (d.j.kind == RJ_LINEAR && d.j.out[0] != nullptr) {
+      const int N = d.j.iv[0], pitch = d.j.iv[1] > 0 ? d.j.iv[1] : N + 1;
+      const long m = q / pitch;
+      const int n = (int)(q - m * pitch);
+      P* dst = (P*)d.j.out[0] + m * N + n;
+      if (n + 3 < N && (reinterpret_cast<uintptr_t>(dst) & (sizeof(P4) - 1)) == 0) {
+        *reinterpret_cast<P4*>(dst) = a;
+        return;
+      }
+    }
+#pragma unroll
+    for (int e = 0; e < 4; ++e) reduce_write<P>(d.j, q + e, a[e]);
+    return;
+  }
   if (d.vec == 4) {   // four consecutive elements per thread, 16-byte (P = float) loads
     typedef P P4 __attribute__((ext_vector_type(4)));
     const long q = ((long)bid * qpb + qi) * 4;
@@ -157,21 +183,31 @@ template <typename P> static int launch_jobs(const ReduceJob* jobs, int n, hipSt
   for (int off = 0; off < n; off += kMaxJobs) {
     ReduceTable t{};
     const int cnt = n - off < kMaxJobs ? n - off : kMaxJobs;
-    int blocks = 0;
     for (int i = 0; i < cnt; ++i) {
       t.d[i].j = jobs[off + i];
       int lanes = 1;
       while (lanes < 16 && lanes < t.d[i].j.S) lanes *= 2;
+      t.d[i].vec = (t.d[i].j.per % 4 == 0 && aligned16(t.d[i].j.in) && (sizeof(P) == 4 || (reinterpret_cast<uintptr_t>(t.d[i].j.in) & 31) == 0)) ? 4 : 1;
+      if (t.d[i].vec == 4 && t.d[i].j.per >= 32768 && (t.d[i].j.kind == RJ_LINEAR || t.d[i].j.kind == RJ_MLP)) lanes = 1;   // (the wide path)
       t.d[i].lanes = lanes;
-      t.d[i].vec = (t.d[i].j.per % 4 == 0 && aligned16(t.d[i].j.in)) ? 4 : 1;
-      const long epb = (long)(256 / lanes) * t.d[i].vec;   // elements per block
-      blocks += (int)((t.d[i].j.per + epb - 1) / epb);
-      t.d[i].blk_end = blocks;
     }
     t.n = cnt;
     const int nfin = (fin != nullptr && off == 0) ? fin->C : 0;   // (rides on the first launch)
+    auto count = [&](int nt) {
+      int b = 0;
+      for (int i = 0; i < cnt; ++i) {
+        const long epb = (long)(nt / t.d[i].lanes) * t.d[i].vec;   // elements per block
+        b += (int)((t.d[i].j.per + epb - 1) / epb);
+        t.d[i].blk_end = b;
+      }
+      return b;
+    };
+    int blocks = count(256);
+    const bool big = nfin > 0 && sizeof(P) == 4 && blocks <= 2048;
+    if (big) blocks = count(1024);
     if (blocks + nfin == 0) continue;
-    multi_reduce_kernel<P><<<blocks + nfin, 256, 0, s>>>(t, nfin ? *fin : FirstFinArgs{}, nfin);
+    if (big) multi_reduce_kernel<P, 1024><<<blocks + nfin, 1024, 0, s>>>(t, *fin, nfin);
+    else multi_reduce_kernel<P, 256><<<blocks + nfin, 256, 0, s>>>(t, nfin ? *fin : FirstFinArgs{}, nfin);
     EMB_CHECK_LAUNCH();
   }
   return EMB_OK;
