@@ -125,6 +125,7 @@ template <typename T, int KS> __global__ __launch_bounds__(256) void head_ce_ker
   const float w1 = (float)(pos_inv / (neg_inv + pos_inv));
   const float w0 = (float)(neg_inv / (neg_inv + pos_inv));
   const double den = (double)w1 * (double)pos + (double)w0 * (double)neg;   // sum_i w[y_i] over the global batch
+  const float g_of[2] = {(float)((double)w0 / den), (float)((double)w1 / den)};   // d loss / d (row's CE term): two values, not one f64 division per row
 
   float wa[KS][4], wb[KS][4];
 #pragma unroll
@@ -192,7 +193,7 @@ template <typename T, int KS> __global__ __launch_bounds__(256) void head_ce_ker
     rows += 1.f;
     if (train) {
       const float inv = 1.0f / (e0 + e1);
-      const float g = (float)((double)wy / den);
+      const float g = y ? g_of[1] : g_of[0];
       const float l0 = g * (e0 * inv - (y ? 0.0f : 1.0f)), l1 = g * (e1 * inv - (y ? 1.0f : 0.0f));
       db0 += l0;
       db1 += l1;
