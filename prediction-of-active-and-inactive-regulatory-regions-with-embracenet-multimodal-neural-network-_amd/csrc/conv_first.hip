@@ -417,13 +417,17 @@ __device__ __forceinline__ void first_body(const FirstArgs& a, const int bm) {
             // the eight channels are eight different columns: all reads first, then the writes (one LDS round trip, not eight).
             // Channels without a gradient (bit 6 / 7 of the code: ReLU zero / dropped) add into the row's pad columns, which
             // nobody reads: no branches
-            float* cell = ft + (sq * L + 2 * p) * FP + c0;
+            // Inside its group of eight, channel e of tile row r sits at position (e + r) & 7: with the natural order the 64 lanes
+            // of one of these accesses (rows 2p + code, groups c0, ONE e) all fall on the 16 banks = e (mod 4) -- the row pitch
+            // and c0 are multiples of 4 -- and the scatter ran 4-way conflicted; rotated by the row they spread over all banks
+            const int r0 = sq * L + 2 * p;
+            float* cell = ft + r0 * FP + c0;
             float cur[8];
             int off[8];
 #pragma unroll
             for (int e = 0; e < 8; ++e) {
               const int code = (int)((aq >> (8 * e)) & 0xFF);
-              off[e] = code < 0x40 ? code * FP + e : BN - c0 + (e & 3);
+              off[e] = code < 0x40 ? code * FP + ((e + r0 + code) & 7) : BN - c0 + (e & 3);
               cur[e] = cell[off[e]];
             }
 #pragma unroll
@@ -435,10 +439,10 @@ __device__ __forceinline__ void first_body(const FirstArgs& a, const int bm) {
       // fp32 -> the bf16 A-operand tile: thread (row, 32-channel half)
       for (int i = threadIdx.x; i < kFBT * (BN / 8); i += NTHR) {
         const int row = i / (BN / 8), c8 = (i - row * (BN / 8)) * 8;
-        const float4 v0 = *reinterpret_cast<const float4*>(ft + row * FP + c8), v1 = *reinterpret_cast<const float4*>(ft + row * FP + c8 + 4);
+        const float* grp = ft + row * FP + c8;             // (the group's channels are rotated by the row, see the scatter)
         bf16x8 o;
-        o[0] = (T)(v0.x * a.keep_scale); o[1] = (T)(v0.y * a.keep_scale); o[2] = (T)(v0.z * a.keep_scale); o[3] = (T)(v0.w * a.keep_scale);
-        o[4] = (T)(v1.x * a.keep_scale); o[5] = (T)(v1.y * a.keep_scale); o[6] = (T)(v1.z * a.keep_scale); o[7] = (T)(v1.w * a.keep_scale);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) o[e] = (T)(grp[(e + row) & 7] * a.keep_scale);
         *reinterpret_cast<bf16x8*>(zt + row * ZP + c8) = o;
       }
     }
