@@ -45,8 +45,14 @@ __device__ __forceinline__ void bn_colsums_f32(const float* __restrict__ partial
       float4 v[16];
 #pragma unroll
       for (int j = 0; j < 16; ++j) v[j] = *reinterpret_cast<const float4*>(src + (long)(r + j * G) * cols);
+      // the sixteen rows meet in f32 (a fixed binary tree: four additions deep), the sixteen-row sums in f64: 1/16 of the f64
+      // conversions and additions, which sit in the prologue of EVERY workgroup of the consuming launch (the partial rows are f32
+      // tile sums already; the tree loses ~2e-7 of a sixteen-row sum, the f64 part keeps E[x^2] - mean^2 benign; bf16 compute only)
 #pragma unroll
-      for (int j = 0; j < 16; ++j) { a0 += (double)v[j].x; a1 += (double)v[j].y; a2 += (double)v[j].z; a3 += (double)v[j].w; }
+      for (int w = 8; w >= 1; w >>= 1)
+#pragma unroll
+        for (int j = 0; j < w; ++j) { v[j].x += v[j + w].x; v[j].y += v[j + w].y; v[j].z += v[j + w].z; v[j].w += v[j + w].w; }
+      a0 += (double)v[0].x; a1 += (double)v[0].y; a2 += (double)v[0].z; a3 += (double)v[0].w;
     }
     for (; r < rows; r += G) {
       const float4 v = *reinterpret_cast<const float4*>(src + (long)r * cols);
