@@ -225,9 +225,11 @@ __device__ __forceinline__ void bn_relu_pool_item(const T* __restrict__ y, const
   constexpr int VEC = Elem<T>::VEC;
   using V = typename Vec16<T>::type;
   const int cv = C / VEC;
-  const int c0 = (int)(i % cv) * VEC;
-  const int p = (int)((i / cv) % Lp);
-  const int b = (int)(i / ((long)cv * Lp));
+  // (32-bit divisions: the launch code refuses B * Lp * C / VEC >= 2^31; three 64-bit divisions per item are ~300 instructions)
+  const unsigned iu = (unsigned)i, q1 = iu / (unsigned)cv;
+  const int c0 = (int)(iu - q1 * (unsigned)cv) * VEC;
+  const int b = (int)(q1 / (unsigned)Lp);
+  const int p = (int)(q1 - (unsigned)b * (unsigned)Lp);
   Acc sc[VEC], sh[VEC], best[VEC];
   int arg[VEC];
 #pragma unroll
@@ -729,6 +731,7 @@ static int convblock_fwd(const void* x, const void* wpack, const void* bias, con
   using P = typename AccOf<T>::type;
   constexpr int VEC = Elem<T>::VEC;
   const ConvWs w = conv_workspace<T>(B, L, cin_pad, Cout, k);
+  EMB_CHECK_ARG((long)B * L * Cout < (1l << 31), "emb_convblock_fwd: B * L * Cout must stay below 2^31 (32-bit element indices)");
   EMB_CHECK_ARG((size_t)ws_bytes >= w.total, "emb_convblock_fwd: workspace too small (%lld < %zu)", (long long)ws_bytes, w.total);
   EMB_CHECK_ARG(cin_pad % VEC == 0 && Cout % VEC == 0, "emb_convblock_fwd: channels must be multiples of %d", VEC);
   const int R = B * L, KK = k * cin_pad, pad = (k - 1) / 2, Lp = (L - kPoolK) / kPoolS + 1;
