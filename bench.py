@@ -743,6 +743,7 @@ def main():
             def step():
                 g_fb.replay()
                 reduce_grads()
+                F.flush_copy()                            # (the captured optimizer launch cannot take a copy parked after its capture)
                 g_opt.replay()
     else:
         step = eager_step
