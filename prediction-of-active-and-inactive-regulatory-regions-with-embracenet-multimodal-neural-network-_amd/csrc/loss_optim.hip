@@ -456,10 +456,12 @@ __device__ __forceinline__ bool opt_update4(const MultiArgs<P>& a, const OptCons
 
 // slab element q of a job -> (output of the job, element of that output); false: padding
 __device__ __forceinline__ bool slab_target(const SlabSrc& j, long q, int* which, long* idx) {
+  // (32-bit divisions: a slab has fewer than 2^31 elements, checked where the job is claimed; 64-bit ones are ~100 instructions each)
   if (j.kind == RJ_LINEAR) {
     const int N = j.iv[0], pitch = j.iv[1] > 0 ? j.iv[1] : N + 1;
-    const long m = q / pitch;
-    const int n = (int)(q - m * pitch);
+    const unsigned qu = (unsigned)q, mu = qu / (unsigned)pitch;
+    const long m = (long)mu;
+    const int n = (int)(qu - mu * (unsigned)pitch);
     if (n > N) return false;
     *which = n == N ? 1 : 0;
     *idx = n == N ? m : m * N + n;
@@ -467,7 +469,7 @@ __device__ __forceinline__ bool slab_target(const SlabSrc& j, long q, int* which
   }
   if (j.kind == RJ_CONV) {
     const int Cin = j.iv[0], cin_pad = j.iv[1], k = j.iv[2], KK = k * cin_pad;
-    const int o = (int)(q / (KK + 1)), col = (int)(q - (long)o * (KK + 1));
+    const int o = (int)((unsigned)q / (unsigned)(KK + 1)), col = (int)((unsigned)q - (unsigned)o * (unsigned)(KK + 1));
     if (col == KK) { *which = 1; *idx = o; return true; }
     const int tap = col / cin_pad, ci = col - tap * cin_pad;
     if (ci >= Cin) return false;
@@ -752,6 +754,7 @@ static int multi_launch(void* const* params, const void* const* grads, void* con
         // a queued slab reduction that would have produced this gradient: its slices are summed in this launch (reduce.h)
         ReduceClaim cl;
         if (plain && reduce_claim(s, grads[j], sizeof(P) == 8, &cl)) {
+          if (cl.job.per >= (1ll << 31)) { set_error("optimizer step: gradient slab of %lld elements", (long long)cl.job.per); return EMB_ERR_ARG; }
           int k = -1;
           for (int q = 0; q < nsrc; ++q)
             if (a.slab[q].in == cl.job.in && a.slab[q].per == cl.job.per) k = q;

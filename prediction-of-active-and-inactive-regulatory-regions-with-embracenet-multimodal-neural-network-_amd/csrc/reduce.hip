@@ -24,13 +24,14 @@ struct ReduceTable {
 template <typename P> __device__ __forceinline__ void reduce_write(const ReduceJob& j, long q, P t) {
   if (j.kind == RJ_LINEAR) {
     const int N = j.iv[0], pitch = j.iv[1] > 0 ? j.iv[1] : N + 1;   // slab row = [N values | bias | padding up to pitch]
-    const long m = q / pitch;
-    const int n = (int)(q - m * pitch);
+    const unsigned qu = (unsigned)q, mu = qu / (unsigned)pitch;     // (slabs have fewer than 2^31 elements: reduce_submit)
+    const long m = (long)mu;
+    const int n = (int)(qu - mu * (unsigned)pitch);
     if (n == N) { if (j.out[1]) ((P*)j.out[1])[m] = t; }
     else if (n < N && j.out[0]) ((P*)j.out[0])[m * N + n] = t;
   } else if (j.kind == RJ_CONV) {   // slab row = [k*cin_pad tap-major columns | bias]; dW in torch layout [Cout][Cin][k]
     const int Cin = j.iv[0], cin_pad = j.iv[1], k = j.iv[2], KK = k * cin_pad;
-    const int o = (int)(q / (KK + 1)), col = (int)(q - (long)o * (KK + 1));
+    const int o = (int)((unsigned)q / (unsigned)(KK + 1)), col = (int)((unsigned)q - (unsigned)o * (unsigned)(KK + 1));
     const int tap = col / cin_pad, ci = col - tap * cin_pad;
     if (col == KK) { if (j.out[1]) ((P*)j.out[1])[o] = t; }
     else if (ci < Cin && j.out[0]) ((P*)j.out[0])[((long)o * Cin + ci) * k + tap] = t;
@@ -103,8 +104,9 @@ template <typename P, int NT> __global__ __launch_bounds__(NT) void multi_reduce
     for (int s = 0; s < d.j.S; ++s) a += *reinterpret_cast<const P4*>(in + (long)s * per + q);
     if (d.j.kind == RJ_LINEAR && d.j.out[0] != nullptr) {
       const int N = d.j.iv[0], pitch = d.j.iv[1] > 0 ? d.j.iv[1] : N + 1;
-      const long m = q / pitch;
-      const int n = (int)(q - m * pitch);
+      const unsigned mu = (unsigned)q / (unsigned)pitch;
+      const long m = (long)mu;
+      const int n = (int)((unsigned)q - mu * (unsigned)pitch);
       P* dst = (P*)d.j.out[0] + m * N + n;
       if (n + 3 < N && (reinterpret_cast<uintptr_t>(dst) & (sizeof(P4) - 1)) == 0) {
         *reinterpret_cast<P4*>(dst) = a;
@@ -348,6 +350,7 @@ bool rider_take(hipStream_t s, int kind, Rider* out) {
 
 int reduce_submit(const ReduceJob& job, bool is_double, hipStream_t s) {
   if (job.per <= 0 || job.S <= 0) return EMB_OK;
+  if (job.per >= (1ll << 31)) { set_error("slab reduction: %lld elements per slice (32-bit element indices)", (long long)job.per); return EMB_ERR_ARG; }
   {
     EMB_LOT(lot, s);
     if (lot.reduce_defer) {
